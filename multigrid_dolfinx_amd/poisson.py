@@ -1,0 +1,256 @@
+"""Synthetic P1 Poisson hierarchies in the conventions of a dolfinx hand-off.
+
+The reference builds its level inputs with dolfinx (`Multigrid_prototype.py:62-118`):
+per level a `UnitSquareMesh`, a CG1 space, Dirichlet data `1 + x^2 + 2y^2` on the
+whole boundary, `assemble_matrix(a, bcs=[bc])` exported with `getValuesCSR()` into a
+SciPy CSR (`:92-96`), a lifted right-hand side reshaped to `(n, 1)` (`:100-110`) and a
+two-way DoF<->coordinate dictionary (`:68-74`).  dolfinx is not installable here, so
+this module synthesises inputs of exactly that shape:
+
+* fp64 values, int32 `indices`/`indptr`, columns sorted within a row (PETSc AIJ),
+* the full P1 sparsity pattern with the numerically-zero couplings kept as explicit
+  0.0 (7 entries per interior row in 2-D, 15 in 3-D),
+* symmetric Dirichlet treatment: boundary rows *and* columns zeroed, 1.0 on the
+  boundary diagonal,
+* right-hand side `f*h^d` on interior nodes, lifted by the boundary data, boundary
+  entries set to the boundary data,
+* an arbitrary DoF numbering (dolfinx numbering is not lexicographic and differs per
+  level, `test/test_mesh.py:36`), related to the grid only through coordinates.
+
+3-D has no reference counterpart; it is the dimension-consistent extension
+(`g = 1 + x^2 + 2y^2 + 3z^2`, `f = -12`, Kuhn 6-tetrahedra split) of SURVEY.md §8(d).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _offsets(dim: int):
+    """P1 sparsity offsets (di, dj[, dk]) in ascending lexicographic-column order."""
+    if dim == 2:
+        offs = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1)]
+        key = lambda o: (o[1], o[0])
+    elif dim == 3:
+        base = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+        offs = [(0, 0, 0)] + base + [tuple(-c for c in o) for o in base]
+        key = lambda o: (o[2], o[1], o[0])
+    else:
+        raise ValueError("dim must be 2 or 3")
+    return sorted(offs, key=key)
+
+
+def boundary_data(coords: np.ndarray, dim: int) -> np.ndarray:
+    """Dirichlet data / exact solution (`Multigrid_prototype.py:78`; 3-D extension)."""
+    g = 1.0 + coords[:, 0] ** 2 + 2.0 * coords[:, 1] ** 2
+    if dim == 3:
+        g = g + 3.0 * coords[:, 2] ** 2
+    return g
+
+
+def source_term(dim: int) -> float:
+    """Constant source `f` (`Multigrid_prototype.py:90`): -6 in 2-D, -12 in 3-D."""
+    return -6.0 if dim == 2 else -12.0
+
+
+@dataclass
+class Level:
+    """One level of a hierarchy, as the reference's script would hand it over."""
+    N: int                      # elements per dimension
+    dim: int
+    A: sp.csr_matrix            # (n, n) fp64 / int32, explicit zeros kept, DoF numbering
+    b: np.ndarray               # (n, 1) lifted right-hand side
+    coords: np.ndarray          # (n, 3) DoF coordinates (z = 0 in 2-D), DoF numbering
+    grid_index: np.ndarray      # (n,) int64: lexicographic node index of each DoF
+    h: float
+
+    @property
+    def n(self) -> int:
+        return self.A.shape[0]
+
+    def exact(self) -> np.ndarray:
+        return boundary_data(self.coords, self.dim).reshape(-1, 1)
+
+
+def lexicographic_level(N: int, dim: int, keep_zeros: bool = True) -> Level:
+    """Assemble one level in lexicographic numbering (x fastest)."""
+    n1 = N + 1
+    n = n1 ** dim
+    h = 1.0 / N
+    if n * 15 >= 2 ** 31 and dim == 3 and keep_zeros:
+        raise ValueError("nnz would overflow int32 indptr; use the device generator")
+    idx = np.arange(n, dtype=np.int64)
+    ijk = [idx % n1, (idx // n1) % n1]
+    if dim == 3:
+        ijk.append(idx // (n1 * n1))
+    on_bnd = np.zeros(n, dtype=bool)
+    for c in ijk:
+        on_bnd |= (c == 0) | (c == N)
+    coords = np.zeros((n, 3))
+    for d in range(dim):
+        coords[:, d] = ijk[d] / N
+    g = boundary_data(coords, dim)
+    w = 1.0 if dim == 2 else h              # magnitude of an axis coupling
+    diag = 4.0 if dim == 2 else 6.0 * h
+    strides = [1, n1, n1 * n1][:dim]
+
+    offs = _offsets(dim)
+    valid, colv, valv = [], [], []
+    b = np.where(on_bnd, g, source_term(dim) * h ** dim)
+    for o in offs:
+        ok = np.ones(n, dtype=bool)
+        delta = 0
+        for d in range(dim):
+            if o[d] > 0:
+                ok &= ijk[d] + o[d] <= N
+            elif o[d] < 0:
+                ok &= ijk[d] + o[d] >= 0
+            delta += o[d] * strides[d]
+        col = idx + delta
+        nz_axis = sum(1 for c in o if c != 0)
+        if nz_axis == 0:
+            val = np.where(on_bnd, 1.0, diag)
+        elif nz_axis == 1:
+            colc = np.clip(col, 0, n - 1)
+            both_int = ok & ~on_bnd & ~on_bnd[colc]
+            val = np.where(both_int, -w, 0.0)
+            lift = ok & ~on_bnd & on_bnd[colc]      # apply_lifting: b -= A_full[:, bc] g
+            b = b + np.where(lift, w * g[colc], 0.0)
+        else:
+            val = np.zeros(n)
+        if not keep_zeros:
+            ok = ok & (val != 0.0)
+        valid.append(ok)
+        colv.append(col)
+        valv.append(val)
+    counts = np.zeros(n, dtype=np.int64)
+    for ok in valid:
+        counts += ok
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float64)
+    pos = indptr[:-1].copy()
+    for ok, col, val in zip(valid, colv, valv):
+        p = pos[ok]
+        indices[p] = col[ok]
+        data[p] = val[ok]
+        pos += ok
+    A = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(n, n))
+    A.has_sorted_indices = True
+    return Level(N=N, dim=dim, A=A, b=b.reshape(n, 1), coords=coords, grid_index=idx.copy(), h=h)
+
+
+def renumber(level: Level, numbering: np.ndarray) -> Level:
+    """Re-express a lexicographic level in the DoF numbering `numbering[p] = dof`."""
+    n = level.n
+    numbering = np.asarray(numbering, dtype=np.int64)
+    grid_index = np.empty(n, dtype=np.int64)
+    grid_index[numbering] = np.arange(n, dtype=np.int64)
+    A = level.A
+    rows = np.repeat(numbering, np.diff(A.indptr))
+    cols = numbering[A.indices]
+    order = np.lexsort((cols, rows))
+    counts = np.bincount(rows, minlength=n)
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(counts, out=indptr[1:])
+    A2 = sp.csr_matrix((A.data[order], cols[order].astype(np.int32), indptr), shape=(n, n))
+    A2.has_sorted_indices = True
+    b = np.empty_like(level.b)
+    b[numbering] = level.b
+    coords = np.empty_like(level.coords)
+    coords[numbering] = level.coords
+    return Level(N=level.N, dim=level.dim, A=A2, b=b, coords=coords, grid_index=grid_index, h=level.h)
+
+
+def make_level(N: int, dim: int, seed: Optional[int] = None, keep_zeros: bool = True) -> Level:
+    """One level; `seed` selects a reproducible random DoF numbering (None = lexicographic)."""
+    lvl = lexicographic_level(N, dim, keep_zeros=keep_zeros)
+    if seed is None:
+        return lvl
+    rng = np.random.default_rng(seed + 7919 * N)
+    return renumber(lvl, rng.permutation(lvl.n))
+
+
+def mesh_dof_dict(level: Level, decimals: int = 9) -> dict:
+    """The reference's two-way dictionary `{dof: xyz} U {xyz: dof}` (`Multigrid_prototype.py:69-74`)."""
+    d = {}
+    for j in range(level.n):
+        tup = tuple(round(float(c), decimals) for c in level.coords[j])
+        d[j] = tup
+        d[tup] = j
+    return d
+
+
+def grid_index_from_coords(coords: np.ndarray, N: int, dim: int) -> np.ndarray:
+    """Lexicographic node index of every DoF from its coordinates.
+
+    This replaces the reference's coordinate hashing (`multigrid.py:71-72`, `:78-79`,
+    `:129-130`); rounding to the nearest grid line is valid for any N, unlike the
+    reference's `int(x / h)` truncation.
+    """
+    coords = np.asarray(coords, dtype=np.float64)
+    n1 = N + 1
+    ijk = np.rint(coords[:, :dim] * N).astype(np.int64)
+    if ijk.min() < 0 or ijk.max() > N:
+        raise ValueError("coordinates outside the unit square/cube")
+    gi = ijk[:, 0] + n1 * ijk[:, 1]
+    if dim == 3:
+        gi = gi + n1 * n1 * ijk[:, 2]
+    if np.unique(gi).size != gi.size:
+        raise ValueError("coordinates do not identify distinct grid nodes")
+    return gi
+
+
+@dataclass
+class Hierarchy:
+    """The 16-field attribute bag of `Var_initializer` (`Multigrid_prototype.py:15-32`)."""
+    mesh_dof_list_dict: Dict[int, dict]
+    element_size: Dict[int, float]
+    coarsest_level_elements_per_dim: int
+    coarsest_level: int
+    finest_level: int
+    A_sp_dict: Dict[int, tuple]
+    A_jacobi_sp_dict: Dict[int, tuple]
+    b_dict: Dict[int, np.ndarray]
+    mu0: int
+    mu1: int
+    mu2: int
+    omega: float
+    residual_per_V_cycle_finest: list = field(default_factory=list)
+    error_per_V_cycle_finest: list = field(default_factory=list)
+    u_exact_fine: object = None
+    V_fine_dolfx: object = None
+    # extras (not part of the reference bag): the generated levels and the dimension
+    levels: Dict[int, Level] = field(default_factory=dict)
+    dim: int = 2
+
+
+def make_hierarchy(dim: int, coarsest_level: int, finest_level: int, c: int = 8,
+                   mu0: int = 2, mu1: int = 50, mu2: int = 50, omega: float = 2.0 / 3.0,
+                   seed: Optional[int] = None, with_dicts: bool = False,
+                   keep_zeros: bool = True) -> Hierarchy:
+    """Level loop of `Multigrid_prototype.py:62-118` on synthetic inputs (N_l = c * 2**l).
+
+    `A_jacobi_sp_dict` is left empty: it is filled by whichever `getJacobiMatrices`
+    (the reference's, the oracle's or the HIP module's) the caller is exercising,
+    as the script does at `Multigrid_prototype.py:135-136`.
+    """
+    levels, dicts, hs, As, bs = {}, {}, {}, {}, {}
+    for l in range(coarsest_level, finest_level + 1):
+        N = c * 2 ** l
+        lvl = make_level(N, dim, seed=seed, keep_zeros=keep_zeros)
+        levels[l] = lvl
+        hs[l] = 1.0 / N
+        As[l] = (lvl.A, l)
+        bs[l] = lvl.b
+        if with_dicts:
+            dicts[l] = mesh_dof_dict(lvl)
+    return Hierarchy(mesh_dof_list_dict=dicts, element_size=hs, coarsest_level_elements_per_dim=c,
+                     coarsest_level=coarsest_level, finest_level=finest_level, A_sp_dict=As,
+                     A_jacobi_sp_dict={}, b_dict=bs, mu0=mu0, mu1=mu1, mu2=mu2, omega=omega,
+                     levels=levels, dim=dim)
