@@ -1,0 +1,195 @@
+/*
+ * mg_hip.h -- C ABI of the MI355X (gfx950) geometric-multigrid V-cycle library
+ * (libmg_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of nikhilTkur/Multigrid_dolfinx.
+ * The reference has no FFI of its own: its boundary is the Python function surface
+ * of multigrid.py.  Each entry point below names the reference interface it
+ * replaces (file:line in the reference).  The only intended caller is the ctypes
+ * shim multigrid_dolfinx_amd/_capi.py; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C types, host pointers, caller owns every buffer it passes in;
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from mg_last_error() (thread-local);
+ *   - levels are numbered 0 (coarsest) .. n_levels-1 (finest); level l has
+ *     N_l = N_0 * 2^l elements per dimension and (N_l+1)^dim unknowns
+ *     (multigrid.py:247-248);
+ *   - vectors crossing the boundary are fp64 in the CALLER's DoF numbering; the
+ *     library keeps them in lexicographic grid numbering internally and permutes
+ *     at this edge using the grid_index given to mg_set_level_csr;
+ *   - one handle = one hierarchy on one GPU (or one slab of it, see mg_set_comm);
+ *     calls on a handle are serialised on the handle's HIP stream; there is no
+ *     global state in the library (the reference's module globals,
+ *     multigrid.py:10-45, live in the Python shim only).
+ */
+#ifndef MG_HIP_H
+#define MG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_context* mg_handle;
+
+/* which per-level device vector an accessor refers to */
+enum mg_vec {
+    MG_VEC_V = 0,   /* iterate / correction v_h                                    */
+    MG_VEC_F = 1,   /* right-hand side f_h (restricted residual on coarse levels)   */
+    MG_VEC_R = 2,   /* residual r_h = f_h - A v_h of the last mg_residual / V-cycle */
+    MG_VEC_ERR = 3  /* interpolated coarse correction err_h (multigrid.py:258-259),  */
+                    /* kept only when mg_set_params(... keep_err = 1)                */
+};
+
+enum mg_restriction {
+    MG_RESTRICT_INJECTION = 0,      /* Restriction2D_direct, multigrid.py:123-132 (the live path, :251-252) */
+    MG_RESTRICT_FULL_WEIGHTING = 1  /* Restriction2D,        multigrid.py:135-198                            */
+};
+
+enum mg_smoother {
+    MG_SMOOTH_JACOBI = 0            /* jacobiRelaxation, multigrid.py:223-228 */
+};
+
+/* ---- life cycle ----------------------------------------------------------------
+ * Replaces the module-global problem state set by initialize_problem
+ * (multigrid.py:28-45) with an explicit handle. */
+int mg_create(int n_levels, int dim, int device, mg_handle* out);
+int mg_destroy(mg_handle h);
+const char* mg_last_error(void);
+/* "gfx950 <n_cus> CUs" style description of the device the handle runs on. */
+int mg_device_info(mg_handle h, char* buf, size_t buflen);
+
+/* ---- multi-GPU (no reference counterpart) -----------------------
+ * One process per GPU.  Must be called before any level is set.  The finest
+ * levels are split into contiguous slabs of grid planes (slowest axis), aligned so
+ * that coarse plane K lives with fine plane 2K; levels with fewer than
+ * `replicate_below` unknowns are replicated on every rank (no communication below
+ * that size).  `nccl_unique_id` is the 128-byte RCCL id obtained on rank 0 with
+ * mg_comm_unique_id and distributed by the caller (bench.py uses torch.distributed
+ * for that rendezvous only).  Halo planes and scalar reductions then travel over
+ * RCCL/xGMI. */
+int mg_comm_unique_id(void* id_out, size_t id_bytes);
+int mg_set_comm(mg_handle h, int rank, int world, const void* nccl_unique_id, size_t id_bytes,
+                int64_t replicate_below);
+/* Host-staged transport for tests without RCCL peers: the library stages device
+ * buffers through host memory and calls back into the caller (who moves the bytes,
+ * e.g. over gloo).  exchange: send `count` doubles to rank-1 / rank+1 (NULL pointer
+ * = no such neighbour) and receive as many from each.  allreduce: in-place sum of
+ * `count` doubles over all ranks.  allgatherv: counts[r] doubles from every rank r
+ * into recv (rank order). */
+typedef int (*mg_exchange_fn)(void* user, const double* send_lo, const double* send_hi,
+                              double* recv_lo, double* recv_hi, int64_t count);
+typedef int (*mg_allreduce_fn)(void* user, double* inout, int64_t count);
+typedef int (*mg_allgatherv_fn)(void* user, const double* send, int64_t send_count,
+                                double* recv, const int64_t* counts);
+int mg_set_comm_callbacks(mg_handle h, int rank, int world, mg_exchange_fn ex, mg_allreduce_fn ar,
+                          mg_allgatherv_fn ag, void* user, int64_t replicate_below);
+
+/* ---- hierarchy set-up --------------------------------------------------------------
+ * mg_set_level_csr: hand over one level's stiffness matrix exactly as
+ * scipy.sparse.csr_matrix((av, aj, ai)) holds it after PETSc getValuesCSR()
+ * (Multigrid_prototype.py:95-99): fp64 values, int32 column indices (possibly
+ * unsorted, possibly with explicit zeros), row pointers int32 or int64
+ * (indptr_is_64).  `grid_index[dof]` is the lexicographic node index
+ * i + (N+1)(j + (N+1)k) of each DoF -- the integer form of the reference's
+ * coordinate dictionaries (Multigrid_prototype.py:68-74); NULL means the DoFs are
+ * already lexicographic.  The library renumbers once (P A P^T), optionally drops
+ * explicit zeros (prune_zeros; the reference's own smoother matrix drops them too,
+ * multigrid.py:52-55, App. A Q7) and stores sliced-ELL tiles.  This subsumes
+ * getJacobiMatrices (multigrid.py:48-56): D^-1 is extracted here and the smoother
+ * streams A itself (v + w D^-1 (f - A v)), so no second matrix is stored.
+ * In slab mode every rank passes the full matrix and keeps its own planes. */
+int mg_set_level_csr(mg_handle h, int level, int elements_per_dim, int64_t n_rows, int64_t nnz,
+                     const void* indptr, int indptr_is_64, const int32_t* indices,
+                     const double* data, const int64_t* grid_index, int prune_zeros);
+/* A level with grid geometry and numbering only (no matrix): enough for the transfer
+ * operators, which the reference exposes as free functions taking two coordinate
+ * dictionaries (Interpolation2D / Restriction2D(_direct), multigrid.py:59, :123, :135). */
+int mg_set_level_grid(mg_handle h, int level, int elements_per_dim, int64_t n_rows,
+                      const int64_t* grid_index);   /* elements_per_dim == 0: flat vector space */
+/* Device-side synthetic generator (bench/tests; no reference counterpart): writes
+ * the same tiles and right-hand side that poisson.make_level + mg_set_level_csr
+ * would produce for the P1 Poisson problem of Multigrid_prototype.py:77-110
+ * (lexicographic numbering), without a host CSR -- the only way to set up 1025^3
+ * unknowns.  Also fills MG_VEC_F with the lifted right-hand side. */
+int mg_gen_poisson_level(mg_handle h, int level, int elements_per_dim, int prune_zeros);
+/* getJacobiMatrices (multigrid.py:48-56) as a stand-alone set-up kernel, for callers that
+ * want the reference's split operands back: for every stored entry a_ij of the CSR matrix
+ * writes scaled[q] = a_ij / a_ii computed as (1/a_ii) * a_ij, keep[q] = 1 unless the entry
+ * is the diagonal or an explicit zero (SciPy's CSR - DIA subtraction drops both, App. A Q7),
+ * and dinv[i] = 1 / a_ii.  The caller compacts the kept entries (the Python shim does, in
+ * SciPy's reversed per-row order) into D^-1 (A - D). */
+int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                    const int32_t* indices, const double* data, double* dinv, double* scaled,
+                    unsigned char* keep);
+/* mu1/mu2/omega: Multigrid_prototype.py:43-46 via initialize_problem
+ * (multigrid.py:38-41).  coarse_rtol/coarse_maxit steer the device PCG that stands
+ * in for spsolve on the coarsest level (multigrid.py:239). */
+int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, int smoother,
+                  double coarse_rtol, int coarse_maxit, int keep_err);
+/* Tuning knobs of the tile kernels (rows per lane, XCD chunking, ...); see DESIGN.md. */
+int mg_set_tuning(mg_handle h, const char* key, int64_t value);
+
+/* ---- level queries ------------------------------------------------------------------- */
+int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, int64_t* row0,
+                  int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated);
+
+/* ---- vectors ---------------------------------------------------------------------------
+ * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the
+ * reference's vectors (Multigrid_prototype.py:110).  In slab mode `host` still has
+ * global length n: set reads the entries of owned (and halo) rows; get writes owned
+ * rows only unless gather != 0, in which case slabs are all-gathered first. */
+int mg_set_vector(mg_handle h, int level, int which, const double* host);
+int mg_get_vector(mg_handle h, int level, int which, double* host, int gather);
+int mg_zero_vector(mg_handle h, int level, int which);
+int mg_copy_vector(mg_handle h, int level, int dst_which, int src_which);
+
+/* ---- the hot path, device-resident --------------------------------------------------------
+ * mg_smooth    nw weighted-Jacobi sweeps on MG_VEC_V            jacobiRelaxation   multigrid.py:223-228
+ * mg_residual  MG_VEC_R = MG_VEC_F - A MG_VEC_V                 multigrid.py:244, :291
+ * mg_restrict  MG_VEC_F[level-1] = R MG_VEC_R[level]            Restriction2D(_direct) multigrid.py:123-198
+ * mg_prolong   MG_VEC_ERR[level] = P MG_VEC_V[level-1]; if add, MG_VEC_V[level] += it
+ *                                                               Interpolation2D    multigrid.py:59-120, :260
+ * mg_coarse_solve  MG_VEC_V[0] = A_0^-1 MG_VEC_F[0]             spsolve            multigrid.py:239-241
+ * mg_vcycle    ncycles V(mu1,mu2) cycles on `level` starting from MG_VEC_V[level];
+ *              resid_l2[c] (optional) = ||f - A v||_2 after cycle c   V_cycle_scheme multigrid.py:231-268
+ * mg_norm2     out = ||x||_2 (all-reduced over slabs)           replaces the l2 part of res_calculator :203-208
+ * mg_fmg       FullMultiGrid(_test): coarsest solve, interpolate up, mu0 cycles per level,
+ *              on the finest either exactly mu0 cycles (tol <= 0; FullMultiGrid_test
+ *              :312-339) or until ||r||_2 <= tol (FullMultiGrid :285-302).  Runs on levels
+ *              0..top_level: MG_VEC_F[top_level] is the right-hand side there, the coarser
+ *              levels use the true right-hand sides given with mg_set_rhs_true (b_dict,
+ *              multigrid.py:279).  elements_per_dim == 0 in mg_set_level_csr declares a
+ *              "flat" level (any square matrix, smoother/residual only, single GPU). */
+int mg_smooth(mg_handle h, int level, int nw);
+int mg_residual(mg_handle h, int level);
+int mg_restrict(mg_handle h, int level, int kind);
+int mg_prolong(mg_handle h, int level, int add);
+int mg_coarse_solve(mg_handle h, int* iterations, double* rel_residual);
+int mg_vcycle(mg_handle h, int level, int ncycles, double* resid_l2);
+int mg_norm2(mg_handle h, int level, int which, double* out);
+/* out = x^T A x for the level's matrix (one tile SpMV fused with the dot product).  With a P1 mass
+ * matrix handed over as the level's matrix this is the square of the reference's L2(Omega) norm
+ * (res_calculator / err_calculator, multigrid.py:203-218). */
+int mg_quadratic_form(mg_handle h, int level, int which, double* out);
+int mg_set_rhs_true(mg_handle h, int level, const double* host);
+int mg_fmg(mg_handle h, int top_level, int mu0, double tol, int max_cycles, double* resid_l2,
+           int* cycles_done);
+
+/* ---- measurement -----------------------------------------------------------------------------
+ * mg_time_kernel: average duration in milliseconds of `reps` back-to-back launches of
+ * one kernel of the path on `level`, measured with HIP events on the handle's own
+ * stream ("jacobi", "residual", "restrict", "prolong", "norm2").  Used by bench.py for
+ * the roofline figure.  mg_sync waits for the handle's stream. */
+int mg_time_kernel(mg_handle h, const char* kernel, int level, int reps, double* avg_ms);
+int mg_sync(mg_handle h);
+/* bytes of device memory held by the handle */
+int mg_memory_bytes(mg_handle h, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_HIP_H */

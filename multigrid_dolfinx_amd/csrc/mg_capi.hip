@@ -1,0 +1,1286 @@
+// C ABI of libmg_hip.so (see include/mg_hip.h): hierarchy handle, level loop of the V-cycle
+// kept on the device, RCCL slab exchange.  Host code only orchestrates launches on the
+// handle's stream; all arithmetic of the path runs in the kernels of mg_kernels.hip.h.
+#include "../../include/mg_hip.h"
+#include "mg_kernels.hip.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mgk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                        ":" + std::to_string(__LINE__) + ")");                                \
+    } while (0)
+
+#define MG_TRY(expr)            \
+    do {                        \
+        int r_ = (expr);        \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+// A device vector in local lexicographic storage: [pad | lower halo | owned rows | upper halo],
+// padded so that the first owned row is 32-byte aligned (the tile kernels load R rows per lane).
+struct DVector {
+    double* raw = nullptr;
+    double* base = nullptr;     // start of [lower halo | owned | upper halo]
+    double* rows = nullptr;     // first owned row = base + lead
+};
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return 0;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(std::string("cannot load librccl: ") + dlerror());
+#define SYM(field, name)                                                      \
+    *reinterpret_cast<void**>(&g_rccl.field) = dlsym(lib, name);              \
+    if (!g_rccl.field) return fail(std::string("librccl lacks ") + name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(Broadcast, "ncclBroadcast");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = lib;
+    return 0;
+}
+
+#define NCCL_TRY(expr)                                                                   \
+    do {                                                                                 \
+        ncclResult_t r_ = (expr);                                                        \
+        if (r_ != ncclSuccess)                                                           \
+            return fail(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));          \
+    } while (0)
+
+struct Comm {
+    int rank = 0, world = 1;
+    int64_t replicate_below = 0;
+    ncclComm_t nccl = nullptr;
+    mg_exchange_fn ex = nullptr;
+    mg_allreduce_fn ar = nullptr;
+    mg_allgatherv_fn ag = nullptr;
+    void* user = nullptr;
+    // pinned host staging for the callback transport
+    double* h_stage = nullptr;
+    size_t h_stage_elems = 0;
+    bool active() const { return world > 1; }
+};
+
+struct Level {
+    bool set = false;
+    bool has_matrix = false;
+    int N = 0;
+    Grid g{};
+    int64_t n_global = 0, row0 = 0, nloc = 0, xlen = 0, halo_lo = 0, halo_hi = 0;
+    bool replicated = true;      // false: this rank holds one slab and exchanges halos
+    bool flat = false;           // no grid structure (stand-alone smoother on any matrix)
+    int W = 0, R = 1;
+    int64_t nslices = 0;
+    double* vals = nullptr;
+    int* cols = nullptr;
+    double* dinv = nullptr;
+    DVector v, v2, f, err, ftrue;
+    int* perm = nullptr;
+    unsigned long long nnz_stored = 0, nnz_nonzero = 0;
+    // per-rank plane ownership (for gathers): k-plane boundaries s[0..world]
+    std::vector<int> splits;
+};
+
+}  // namespace
+
+struct mg_context {
+    int dim = 2, nlev = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Level> L;
+    int mu1 = 50, mu2 = 50;
+    double omega = 2.0 / 3.0;
+    int restriction = MG_RESTRICT_INJECTION, smoother = MG_SMOOTH_JACOBI;
+    double coarse_rtol = 1e-14;
+    int coarse_maxit = 20000;
+    int keep_err = 0;
+    // tuning
+    int rows_per_lane = 1;
+    unsigned chunk = 1;
+    int pcg_chunk = 16;
+    // scratch
+    double* partials = nullptr;     // 2 * kMaxParts doubles
+    double* scalars = nullptr;      // 8 doubles
+    int* done = nullptr;
+    double* h_scalars = nullptr;    // pinned, 8 doubles + flag
+    double *pcg_r = nullptr, *pcg_z = nullptr, *pcg_q = nullptr, *pcg_part_a = nullptr, *pcg_part_b = nullptr;
+    DVector pcg_p;
+    int pcg_parts = 0, pcg_parts_a = 0;
+    int pcg_predict = 0;
+    double* stage = nullptr;        // device staging for host vectors (caller numbering)
+    int64_t stage_elems = 0;
+    int64_t bytes = 0;
+    Comm comm;
+    hipDeviceProp_t prop{};
+};
+
+namespace {
+
+constexpr int kMaxParts = 1024;
+
+template <class T>
+int dev_alloc(mg_context* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    c->bytes += (int64_t)(count * sizeof(T));
+    return 0;
+}
+
+template <class T>
+void dev_free(mg_context* c, T*& p, size_t count) {
+    if (p) {
+        (void)hipFree(p);
+        c->bytes -= (int64_t)((count ? count : 1) * sizeof(T));
+        p = nullptr;
+    }
+}
+
+int vec_alloc(mg_context* c, const Level& L, DVector* v) {
+    if (v->raw) return 0;
+    const int64_t pad = (4 - (L.g.lead % 4)) % 4;
+    MG_TRY(dev_alloc(c, &v->raw, (size_t)(L.xlen + pad + 4)));
+    v->base = v->raw + pad;
+    v->rows = v->base + L.g.lead;
+    HIP_TRY(hipMemsetAsync(v->raw, 0, (size_t)(L.xlen + pad + 4) * sizeof(double), c->stream));
+    return 0;
+}
+
+void vec_free(mg_context* c, const Level& L, DVector* v) {
+    if (v->raw) {
+        const int64_t pad = (4 - (L.g.lead % 4)) % 4;
+        dev_free(c, v->raw, (size_t)(L.xlen + pad + 4));
+        v->base = v->rows = nullptr;
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+dim3 grid3(const Grid& g, int nk) { return dim3((unsigned)((g.nx + 127) / 128), (unsigned)g.ny, (unsigned)nk); }
+
+int check_level(mg_context* c, int level, bool must_be_set = true) {
+    if (!c) return fail("null handle");
+    if (level < 0 || level >= c->nlev) return fail("level " + std::to_string(level) + " out of range");
+    if (must_be_set && !c->L[level].set) return fail("level " + std::to_string(level) + " has not been set");
+    return 0;
+}
+
+int need_matrix(mg_context* c, int level) {
+    MG_TRY(check_level(c, level));
+    if (!c->L[level].has_matrix) return fail("level " + std::to_string(level) + " has no matrix (grid-only level)");
+    return 0;
+}
+
+int need_grid(mg_context* c, int level) {
+    MG_TRY(check_level(c, level));
+    if (c->L[level].flat) return fail("level " + std::to_string(level) + " is flat (no grid): transfers are undefined");
+    return 0;
+}
+
+// ---- slab geometry ---------------------------------------------------------------------------
+// Plane boundaries on the coarsest grid t_g = floor(g*N0/G) (t_G = N0+1); level l uses
+// t_g * 2^l, so coarse plane K and fine plane 2K always live on the same rank.
+int setup_geometry(mg_context* c, int level, int N, int64_t flat_rows = 0) {
+    Level& L = c->L[level];
+    const int dim = c->dim;
+    const Comm& cm = c->comm;
+    Grid& g = L.g;
+    L.flat = N == 0;
+    if (L.flat) {
+        // any square matrix: one "plane" holding every row; smoother / residual only
+        if (cm.active()) return fail("flat levels are single-GPU only");
+        if (flat_rows <= 0 || flat_rows >= (int64_t)INT32_MAX) return fail("bad row count");
+        L.N = 0;
+        g.nx = (int)flat_rows; g.ny = 1; g.nz = 1; g.plane = flat_rows; g.refine_y = 0;
+        g.k0 = 0; g.nk = 1; g.lead = 0;
+        L.n_global = L.nloc = L.xlen = flat_rows;
+        L.row0 = L.halo_lo = L.halo_hi = 0;
+        L.replicated = true;
+        L.splits.assign(2, 0);
+        L.splits[1] = 1;
+        return 0;
+    }
+    L.N = N;
+    g.nx = N + 1;
+    g.ny = dim == 3 ? N + 1 : 1;
+    g.nz = N + 1;
+    g.plane = (int64_t)g.nx * g.ny;
+    g.refine_y = dim == 3 ? 1 : 0;
+    L.n_global = g.plane * g.nz;
+    if (L.n_global >= (int64_t)INT32_MAX) return fail("level has more than 2^31-1 unknowns");
+    L.replicated = !(cm.active() && L.n_global >= cm.replicate_below);
+    if (level == 0 && cm.active()) L.replicated = true;      // the coarsest solve is never distributed
+    L.splits.assign(cm.world + 1, 0);
+    if ((N >> level) << level != N) return fail("elements_per_dim is not N0 * 2^level");
+    const int N0 = N >> level;
+    for (int r = 0; r < cm.world; ++r) L.splits[r] = (int)(((int64_t)r * N0) / cm.world) << level;
+    L.splits[cm.world] = N + 1;
+    if (!L.replicated) {
+        if (N0 < cm.world) return fail("coarsest grid has fewer planes than ranks");
+        g.k0 = L.splits[cm.rank];
+        g.nk = L.splits[cm.rank + 1] - g.k0;
+        L.halo_lo = cm.rank > 0 ? g.plane : 0;
+        L.halo_hi = cm.rank + 1 < cm.world ? g.plane : 0;
+    } else {
+        g.k0 = 0;
+        g.nk = g.nz;
+        L.halo_lo = L.halo_hi = 0;
+    }
+    g.lead = L.halo_lo;
+    L.row0 = (int64_t)g.k0 * g.plane;
+    L.nloc = (int64_t)g.nk * g.plane;
+    L.xlen = L.halo_lo + L.nloc + L.halo_hi;
+    return 0;
+}
+
+int alloc_level_vectors(mg_context* c, Level& L) {
+    MG_TRY(vec_alloc(c, L, &L.v));
+    MG_TRY(vec_alloc(c, L, &L.v2));
+    MG_TRY(vec_alloc(c, L, &L.f));
+    return 0;
+}
+
+void free_level(mg_context* c, Level& L) {
+    if (!L.set && !L.vals) return;
+    const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
+    dev_free(c, L.vals, ell);
+    dev_free(c, L.cols, ell);
+    dev_free(c, L.dinv, (size_t)L.nslices * WAVE * L.R);
+    dev_free(c, L.perm, (size_t)L.n_global);
+    vec_free(c, L, &L.v);
+    vec_free(c, L, &L.v2);
+    vec_free(c, L, &L.f);
+    vec_free(c, L, &L.err);
+    vec_free(c, L, &L.ftrue);
+    L.set = false;
+    L.has_matrix = false;
+}
+
+// ---- tile kernel dispatch --------------------------------------------------------------------
+template <int WT, int R>
+void launch_ell_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (mode == MODE_RESIDUAL)
+        hipLaunchKernelGGL((ell_apply<WT, R, MODE_RESIDUAL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_JACOBI)
+        hipLaunchKernelGGL((ell_apply<WT, R, MODE_JACOBI, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (dot)
+        hipLaunchKernelGGL((ell_apply<WT, R, MODE_SPMV, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((ell_apply<WT, R, MODE_SPMV, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
+template <int R>
+void launch_ell_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+    switch (W) {
+        case 5: launch_ell_wr<5, R>(mode, dot, a, grid, s); break;
+        case 7: launch_ell_wr<7, R>(mode, dot, a, grid, s); break;
+        case 15: launch_ell_wr<15, R>(mode, dot, a, grid, s); break;
+        default: launch_ell_wr<0, R>(mode, dot, a, grid, s); break;
+    }
+}
+
+// out = op(A, x) over all owned slices of the level
+int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
+               double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr) {
+    EllArgs a{};
+    a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
+    a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
+    a.slice0 = 0; a.nslices = L.nslices; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
+    const unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
+    if (grid_out) *grid_out = grid;
+    switch (L.R) {
+        case 1: launch_ell_r<1>(L.W, mode, dot, a, grid, c->stream); break;
+        case 2: launch_ell_r<2>(L.W, mode, dot, a, grid, c->stream); break;
+        case 4: launch_ell_r<4>(L.W, mode, dot, a, grid, c->stream); break;
+        default: return fail("unsupported rows_per_lane");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- communication -----------------------------------------------------------------------------
+int ensure_host_stage(mg_context* c, size_t elems) {
+    Comm& cm = c->comm;
+    if (cm.h_stage_elems >= elems) return 0;
+    if (cm.h_stage) (void)hipHostFree(cm.h_stage);
+    cm.h_stage = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cm.h_stage), elems * sizeof(double), hipHostMallocDefault));
+    cm.h_stage_elems = elems;
+    return 0;
+}
+
+// Fill both halo planes of `v` from the neighbouring slabs (first owned plane goes down,
+// last owned plane goes up).
+int exchange_halo(mg_context* c, const Level& L, DVector& v) {
+    Comm& cm = c->comm;
+    if (L.replicated || !cm.active()) return 0;
+    const size_t plane = (size_t)L.g.plane;
+    const bool lo = cm.rank > 0, hi = cm.rank + 1 < cm.world;
+    double* send_lo = v.rows;
+    double* send_hi = v.rows + L.nloc - plane;
+    double* recv_lo = v.base;
+    double* recv_hi = v.rows + L.nloc;
+    if (cm.nccl) {
+        NCCL_TRY(g_rccl.GroupStart());
+        if (lo) {
+            NCCL_TRY(g_rccl.Send(send_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, c->stream));
+            NCCL_TRY(g_rccl.Recv(recv_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, c->stream));
+        }
+        if (hi) {
+            NCCL_TRY(g_rccl.Send(send_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, c->stream));
+            NCCL_TRY(g_rccl.Recv(recv_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, c->stream));
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+        return 0;
+    }
+    if (!cm.ex) return fail("no transport configured");
+    MG_TRY(ensure_host_stage(c, 4 * plane));
+    double* h = cm.h_stage;
+    if (lo) HIP_TRY(hipMemcpyAsync(h, send_lo, plane * 8, hipMemcpyDeviceToHost, c->stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(h + plane, send_hi, plane * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cm.ex(cm.user, lo ? h : nullptr, hi ? h + plane : nullptr, lo ? h + 2 * plane : nullptr,
+              hi ? h + 3 * plane : nullptr, (int64_t)plane) != 0)
+        return fail("exchange callback failed");
+    if (lo) HIP_TRY(hipMemcpyAsync(recv_lo, h + 2 * plane, plane * 8, hipMemcpyHostToDevice, c->stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(recv_hi, h + 3 * plane, plane * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// In-place sum of `count` device doubles over all ranks.
+int allreduce_sum(mg_context* c, double* dev, int64_t count) {
+    Comm& cm = c->comm;
+    if (!cm.active()) return 0;
+    if (cm.nccl) {
+        NCCL_TRY(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, cm.nccl, c->stream));
+        return 0;
+    }
+    if (!cm.ar) return fail("no transport configured");
+    MG_TRY(ensure_host_stage(c, (size_t)count));
+    HIP_TRY(hipMemcpyAsync(cm.h_stage, dev, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cm.ar(cm.user, cm.h_stage, count) != 0) return fail("allreduce callback failed");
+    HIP_TRY(hipMemcpyAsync(dev, cm.h_stage, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// `full` holds every plane of a level (global lexicographic order); each rank has written the
+// planes [splits[rank], splits[rank+1]) and receives the others.
+int allgather_planes(mg_context* c, const std::vector<int>& splits, int64_t plane, double* full) {
+    Comm& cm = c->comm;
+    if (!cm.active()) return 0;
+    if (cm.nccl) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int r = 0; r < cm.world; ++r) {
+            double* seg = full + (int64_t)splits[r] * plane;
+            const size_t cnt = (size_t)(splits[r + 1] - splits[r]) * (size_t)plane;
+            NCCL_TRY(g_rccl.Broadcast(seg, seg, cnt, ncclDouble, r, cm.nccl, c->stream));
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+        return 0;
+    }
+    if (!cm.ag) return fail("no transport configured");
+    const int64_t total = (int64_t)splits[cm.world] * plane;
+    const int64_t mine = (int64_t)(splits[cm.rank + 1] - splits[cm.rank]) * plane;
+    MG_TRY(ensure_host_stage(c, (size_t)(total + mine)));
+    double* h_send = cm.h_stage + total;
+    HIP_TRY(hipMemcpyAsync(h_send, full + (int64_t)splits[cm.rank] * plane, (size_t)mine * 8, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int64_t> counts(cm.world);
+    for (int r = 0; r < cm.world; ++r) counts[r] = (int64_t)(splits[r + 1] - splits[r]) * plane;
+    if (cm.ag(cm.user, h_send, mine, cm.h_stage, counts.data()) != 0) return fail("allgatherv callback failed");
+    HIP_TRY(hipMemcpyAsync(full, cm.h_stage, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- the path ----------------------------------------------------------------------------------------
+DVector* pick(Level& L, int which) {
+    switch (which) {
+        case MG_VEC_V: return &L.v;
+        case MG_VEC_F: return &L.f;
+        case MG_VEC_R: return &L.v2;
+        case MG_VEC_ERR: return &L.err;
+        default: return nullptr;
+    }
+}
+
+// nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
+int smooth(mg_context* c, int level, int nw) {
+    Level& L = c->L[level];
+    for (int s = 0; s < nw; ++s) {
+        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
+        std::swap(L.v, L.v2);
+        MG_TRY(exchange_halo(c, L, L.v));
+    }
+    return 0;
+}
+
+int residual(mg_context* c, int level) {
+    Level& L = c->L[level];
+    return launch_ell(c, L, MODE_RESIDUAL, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
+}
+
+// Grid of the coarse planes this rank produces when restricting from `fine`: its own slab if the
+// coarse level is distributed, otherwise the planes matching its fine slab inside the replica.
+Grid coarse_target_grid(const mg_context* c, const Level& C, const Level& F) {
+    Grid g = C.g;
+    if (C.replicated && !F.replicated) {
+        g.k0 = C.splits[c->comm.rank];
+        g.nk = C.splits[c->comm.rank + 1] - g.k0;
+        g.lead = (int64_t)g.k0 * g.plane;
+    }
+    return g;
+}
+
+int restrict_to(mg_context* c, int level, int kind) {
+    Level& F = c->L[level];
+    Level& C = c->L[level - 1];
+    Grid gc = coarse_target_grid(c, C, F);
+    if (kind == MG_RESTRICT_FULL_WEIGHTING) {
+        MG_TRY(exchange_halo(c, F, F.v2));
+        hipLaunchKernelGGL(restrict_full_weighting, grid3(gc, gc.nk), dim3(128), 0, c->stream, gc, F.g, F.v2.base,
+                           C.f.base);
+    } else {
+        hipLaunchKernelGGL(restrict_inject, grid3(gc, gc.nk), dim3(128), 0, c->stream, gc, F.g, F.v2.base, C.f.base);
+    }
+    HIP_TRY(hipGetLastError());
+    if (C.replicated && !F.replicated) MG_TRY(allgather_planes(c, C.splits, C.g.plane, C.f.base));
+    return 0;
+}
+
+int prolong(mg_context* c, int level, int add) {
+    Level& F = c->L[level];
+    Level& C = c->L[level - 1];
+    const bool keep = !add || c->keep_err;
+    if (keep) MG_TRY(vec_alloc(c, F, &F.err));
+    const dim3 grid = grid3(F.g, F.g.nk);
+    if (add && keep)
+        hipLaunchKernelGGL((prolong_correct<true, true>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
+    else if (add)
+        hipLaunchKernelGGL((prolong_correct<true, false>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((prolong_correct<false, true>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
+    HIP_TRY(hipGetLastError());
+    if (add) MG_TRY(exchange_halo(c, F, F.v));
+    return 0;
+}
+
+int zero_vec(mg_context* c, const Level& L, DVector& v) {
+    HIP_TRY(hipMemsetAsync(v.base, 0, (size_t)L.xlen * sizeof(double), c->stream));
+    return 0;
+}
+
+// sum over owned rows of x.y on the device -> c->scalars[slot]; all-reduced over slabs
+int dot_device(mg_context* c, const Level& L, const double* x_rows, const double* y_rows, int slot) {
+    const int np = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (L.nloc + 2 * BLOCK - 1) / (2 * BLOCK)));
+    hipLaunchKernelGGL(dot_partial, dim3(np), dim3(BLOCK), 0, c->stream, x_rows, y_rows, L.nloc, c->partials);
+    hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(BLOCK), 0, c->stream, c->partials, np, c->scalars + slot);
+    HIP_TRY(hipGetLastError());
+    if (!L.replicated) MG_TRY(allreduce_sum(c, c->scalars + slot, 1));
+    return 0;
+}
+
+int norm2(mg_context* c, const Level& L, const double* x_rows, double* out) {
+    MG_TRY(dot_device(c, L, x_rows, x_rows, 0));
+    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = std::sqrt(c->h_scalars[0]);
+    return 0;
+}
+
+// Coarsest level: v = A^-1 f by Jacobi-preconditioned CG run to `coarse_rtol`; stands in for the
+// reference's exact spsolve (multigrid.py:239-241).  Iterations are enqueued in batches; only the
+// 4-byte convergence flag crosses to the host between batches.
+int coarse_solve(mg_context* c, int* iters_out, double* rel_out) {
+    Level& L = c->L[0];
+    if (L.g.lead != 0) return fail("coarsest level must not be distributed");
+    const int64_t n = L.nloc;
+    if (!c->pcg_r) {
+        MG_TRY(dev_alloc(c, &c->pcg_r, (size_t)n + 4));
+        MG_TRY(dev_alloc(c, &c->pcg_z, (size_t)n + 4));
+        MG_TRY(dev_alloc(c, &c->pcg_q, (size_t)n + 4));
+        MG_TRY(vec_alloc(c, L, &c->pcg_p));
+        c->pcg_parts = (int)std::min<int64_t>(512, std::max<int64_t>(1, (n + BLOCK - 1) / BLOCK));
+        c->pcg_parts_a = (int)std::max<unsigned>(blocks_for(L.nslices, WAVES_PER_BLOCK), (unsigned)c->pcg_parts);
+        MG_TRY(dev_alloc(c, &c->pcg_part_a, (size_t)c->pcg_parts_a));
+        MG_TRY(dev_alloc(c, &c->pcg_part_b, (size_t)2 * c->pcg_parts));
+    }
+    PcgArgs a{};
+    a.x = L.v.rows; a.r = c->pcg_r; a.z = c->pcg_z; a.p = c->pcg_p.rows; a.q = c->pcg_q;
+    a.b = L.f.rows; a.dinv = L.dinv; a.part_a = c->pcg_part_a; a.part_b = c->pcg_part_b;
+    a.nparts = c->pcg_parts; a.sc = c->scalars; a.done = c->done; a.n = n;
+    a.rtol2 = c->coarse_rtol * c->coarse_rtol;
+    const dim3 grid(c->pcg_parts), blk(BLOCK);
+    hipLaunchKernelGGL(pcg_init, grid, blk, 0, c->stream, a);
+    hipLaunchKernelGGL(pcg_init_finish, dim3(1), blk, 0, c->stream, a);
+    int it = 0;
+    int batch = c->pcg_predict > 0 ? c->pcg_predict : c->pcg_chunk;
+    int* h_done = reinterpret_cast<int*>(c->h_scalars + 8);
+    for (;;) {
+        batch = std::min(batch, c->coarse_maxit - it);
+        for (int b = 0; b < batch; ++b) {
+            unsigned np_spmv = 0;
+            MG_TRY(launch_ell(c, L, MODE_SPMV, true, c->pcg_p.base, nullptr, c->pcg_q, c->pcg_part_a, c->done, &np_spmv));
+            hipLaunchKernelGGL(pcg_update, grid, blk, 0, c->stream, a, (int)np_spmv);
+            hipLaunchKernelGGL(pcg_direction, grid, blk, 0, c->stream, a);
+            hipLaunchKernelGGL(pcg_scalars, dim3(1), blk, 0, c->stream, a);
+        }
+        it += batch;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_done, c->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*h_done || it >= c->coarse_maxit) break;
+        batch = c->pcg_chunk;
+    }
+    const int used = (int)c->h_scalars[5];
+    const double bb = c->h_scalars[3], rr = c->h_scalars[2];
+    const double rel = bb > 0.0 ? std::sqrt(rr / bb) : 0.0;
+    if (iters_out) *iters_out = used;
+    if (rel_out) *rel_out = rel;
+    if (!*h_done)
+        return fail("coarse solve did not converge: " + std::to_string(used) + " iterations, relative residual " +
+                    std::to_string(rel));
+    c->pcg_predict = used;
+    return 0;
+}
+
+// One V(mu1, mu2) cycle on `level` (V_cycle_scheme, multigrid.py:231-268): pre-smooth, residual,
+// restrict, recurse from a zero guess, interpolate + correct, post-smooth; exact solve on level 0.
+int vcycle(mg_context* c, int level) {
+    if (level == 0) return coarse_solve(c, nullptr, nullptr);
+    Level& C = c->L[level - 1];
+    MG_TRY(smooth(c, level, c->mu1));
+    MG_TRY(residual(c, level));
+    MG_TRY(restrict_to(c, level, c->restriction));
+    MG_TRY(zero_vec(c, C, C.v));
+    MG_TRY(vcycle(c, level - 1));
+    MG_TRY(prolong(c, level, 1));
+    MG_TRY(smooth(c, level, c->mu2));
+    return 0;
+}
+
+int ensure_stage(mg_context* c, int64_t elems) {
+    if (c->stage_elems >= elems) return 0;
+    dev_free(c, c->stage, (size_t)c->stage_elems);
+    c->stage_elems = 0;
+    MG_TRY(dev_alloc(c, &c->stage, (size_t)elems));
+    c->stage_elems = elems;
+    return 0;
+}
+
+int upload_vector(mg_context* c, Level& L, DVector& v, const double* host) {
+    MG_TRY(ensure_stage(c, L.n_global));
+    HIP_TRY(hipMemcpyAsync(c->stage, host, (size_t)L.n_global * 8, hipMemcpyHostToDevice, c->stream));
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (L.n_global + 255) / 256);
+    hipLaunchKernelGGL(scatter_in, dim3(nb), dim3(256), 0, c->stream, c->stage, L.perm, L.n_global, L.row0, L.g.lead,
+                       L.xlen, v.base);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int finish_level(mg_context* c, Level& L) {
+    MG_TRY(alloc_level_vectors(c, L));
+    L.set = true;
+    return 0;
+}
+
+int alloc_ell(mg_context* c, Level& L) {
+    L.R = c->rows_per_lane;
+    L.nslices = (L.nloc + (int64_t)WAVE * L.R - 1) / ((int64_t)WAVE * L.R);
+    const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
+    MG_TRY(dev_alloc(c, &L.vals, ell));
+    MG_TRY(dev_alloc(c, &L.cols, ell));
+    MG_TRY(dev_alloc(c, &L.dinv, (size_t)L.nslices * WAVE * L.R));
+    const unsigned nb = blocks_for((int64_t)ell, 256);
+    switch (L.R) {
+        case 1: hipLaunchKernelGGL(ell_fill_padding<1>, dim3(nb), dim3(256), 0, c->stream, L.vals, L.cols, L.nslices, L.W, L.nloc, L.g.lead); break;
+        case 2: hipLaunchKernelGGL(ell_fill_padding<2>, dim3(nb), dim3(256), 0, c->stream, L.vals, L.cols, L.nslices, L.W, L.nloc, L.g.lead); break;
+        case 4: hipLaunchKernelGGL(ell_fill_padding<4>, dim3(nb), dim3(256), 0, c->stream, L.vals, L.cols, L.nslices, L.W, L.nloc, L.g.lead); break;
+        default: return fail("rows_per_lane must be 1, 2 or 4");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+void sorted_offsets(int dim, int out[15][3], int* n) {
+    std::vector<std::array<int, 3>> offs;
+    if (dim == 2) {
+        const int b[3][2] = {{1, 0}, {0, 1}, {1, 1}};
+        offs.push_back({0, 0, 0});
+        for (auto& o : b) {
+            offs.push_back({o[0], 0, o[1]});
+            offs.push_back({-o[0], 0, -o[1]});
+        }
+    } else {
+        const int b[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+        offs.push_back({0, 0, 0});
+        for (auto& o : b) {
+            offs.push_back({o[0], o[1], o[2]});
+            offs.push_back({-o[0], -o[1], -o[2]});
+        }
+    }
+    std::sort(offs.begin(), offs.end(), [](const std::array<int, 3>& a, const std::array<int, 3>& b) {
+        if (a[2] != b[2]) return a[2] < b[2];
+        if (a[1] != b[1]) return a[1] < b[1];
+        return a[0] < b[0];
+    });
+    *n = (int)offs.size();
+    for (int t = 0; t < *n; ++t)
+        for (int d = 0; d < 3; ++d) out[t][d] = offs[t][d];
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* mg_last_error(void) { return g_err.c_str(); }
+
+int mg_create(int n_levels, int dim, int device, mg_handle* out) {
+    if (!out) return fail("null output handle");
+    *out = nullptr;
+    if (n_levels < 1 || n_levels > 32) return fail("n_levels must be in 1..32");
+    if (dim != 2 && dim != 3) return fail("dim must be 2 or 3");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("no HIP device visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail("device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mg_context* c = new mg_context();
+    c->dim = dim;
+    c->nlev = n_levels;
+    c->device = device;
+    c->L.resize(n_levels);
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MG_TRY(dev_alloc(c, &c->partials, 2 * kMaxParts));
+    MG_TRY(dev_alloc(c, &c->scalars, 8));
+    MG_TRY(dev_alloc(c, &c->done, 1));
+    HIP_TRY(hipMemsetAsync(c->done, 0, sizeof(int), c->stream));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 16 * sizeof(double), hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+int mg_destroy(mg_handle c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& L : c->L) free_level(c, L);
+    (void)hipFree(c->partials);
+    (void)hipFree(c->scalars);
+    (void)hipFree(c->done);
+    (void)hipFree(c->pcg_r);
+    (void)hipFree(c->pcg_z);
+    (void)hipFree(c->pcg_q);
+    (void)hipFree(c->pcg_p.raw);
+    (void)hipFree(c->pcg_part_a);
+    (void)hipFree(c->pcg_part_b);
+    (void)hipFree(c->stage);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->comm.h_stage) (void)hipHostFree(c->comm.h_stage);
+    if (c->comm.nccl) g_rccl.CommDestroy(c->comm.nccl);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int mg_device_info(mg_handle c, char* buf, size_t buflen) {
+    if (!c || !buf || buflen == 0) return fail("bad arguments");
+    snprintf(buf, buflen, "%s %s %d CUs %.1f GiB", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount,
+             (double)c->prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return 0;
+}
+
+int mg_comm_unique_id(void* id_out, size_t id_bytes) {
+    if (!id_out || id_bytes < sizeof(ncclUniqueId)) return fail("id buffer must hold 128 bytes");
+    MG_TRY(load_rccl());
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+static int comm_common(mg_handle c, int rank, int world, int64_t replicate_below) {
+    if (!c) return fail("null handle");
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
+    for (auto& L : c->L)
+        if (L.set) return fail("mg_set_comm must precede level set-up");
+    c->comm.rank = rank;
+    c->comm.world = world;
+    c->comm.replicate_below = replicate_below;
+    return 0;
+}
+
+int mg_set_comm(mg_handle c, int rank, int world, const void* nccl_unique_id, size_t id_bytes, int64_t replicate_below) {
+    MG_TRY(comm_common(c, rank, world, replicate_below));
+    if (world == 1) return 0;
+    if (!nccl_unique_id || id_bytes < sizeof(ncclUniqueId)) return fail("missing RCCL unique id");
+    MG_TRY(load_rccl());
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, nccl_unique_id, sizeof(id));
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm.nccl, world, id, rank));
+    return 0;
+}
+
+int mg_set_comm_callbacks(mg_handle c, int rank, int world, mg_exchange_fn ex, mg_allreduce_fn ar, mg_allgatherv_fn ag,
+                          void* user, int64_t replicate_below) {
+    MG_TRY(comm_common(c, rank, world, replicate_below));
+    if (world > 1 && (!ex || !ar || !ag)) return fail("all three callbacks are required");
+    c->comm.ex = ex;
+    c->comm.ar = ar;
+    c->comm.ag = ag;
+    c->comm.user = user;
+    return 0;
+}
+
+int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, int smoother, double coarse_rtol,
+                  int coarse_maxit, int keep_err) {
+    if (!c) return fail("null handle");
+    if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
+    if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
+    if (smoother != MG_SMOOTH_JACOBI) return fail("unknown smoother");
+    c->mu1 = mu1; c->mu2 = mu2; c->omega = omega; c->restriction = restriction; c->smoother = smoother;
+    if (coarse_rtol > 0) c->coarse_rtol = coarse_rtol;
+    if (coarse_maxit > 0) c->coarse_maxit = coarse_maxit;
+    c->keep_err = keep_err;
+    return 0;
+}
+
+int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
+    if (!c || !key) return fail("bad arguments");
+    const std::string k(key);
+    if (k == "rows_per_lane") {
+        if (value != 1 && value != 2 && value != 4) return fail("rows_per_lane must be 1, 2 or 4");
+        for (auto& L : c->L)
+            if (L.set) return fail("rows_per_lane must be chosen before level set-up");
+        c->rows_per_lane = (int)value;
+    } else if (k == "xcd_chunk") {
+        if (value < 1 || value > 4096) return fail("xcd_chunk out of range");
+        c->chunk = (unsigned)value;
+    } else if (k == "pcg_chunk") {
+        if (value < 1) return fail("pcg_chunk must be positive");
+        c->pcg_chunk = (int)value;
+    } else {
+        return fail("unknown tuning key " + k);
+    }
+    return 0;
+}
+
+int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                     const int32_t* indices, const double* data, const int64_t* grid_index, int prune_zeros) {
+    MG_TRY(check_level(c, level, false));
+    if (!indptr || !indices || !data) return fail("null CSR arrays");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, level, N, n_rows));
+    if (n_rows != L.n_global)
+        return fail("matrix has " + std::to_string(n_rows) + " rows, grid has " + std::to_string(L.n_global));
+    // upload the hand-off
+    void* d_ptr = nullptr;
+    int* d_idx = nullptr;
+    double* d_val = nullptr;
+    const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
+    HIP_TRY(hipMalloc(&d_ptr, ptr_bytes));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), std::max<size_t>(1, (size_t)nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_val), std::max<size_t>(1, (size_t)nnz) * 8));
+    auto cleanup = [&]() { (void)hipFree(d_ptr); (void)hipFree(d_idx); (void)hipFree(d_val); };
+    HIP_TRY(hipMemcpyAsync(d_ptr, indptr, ptr_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_idx, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_val, data, (size_t)nnz * 8, hipMemcpyHostToDevice, c->stream));
+    if (grid_index) {
+        std::vector<int> p32((size_t)n_rows);
+        std::vector<char> seen((size_t)n_rows, 0);
+        for (int64_t d = 0; d < n_rows; ++d) {
+            const int64_t p = grid_index[d];
+            if (p < 0 || p >= n_rows || seen[(size_t)p]) { cleanup(); return fail("grid_index is not a permutation of the grid nodes"); }
+            seen[(size_t)p] = 1;
+            p32[(size_t)d] = (int)p;
+        }
+        if (dev_alloc(c, &L.perm, (size_t)n_rows)) { cleanup(); return 1; }
+        HIP_TRY(hipMemcpy(L.perm, p32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    }
+    CsrArgs a{};
+    a.indptr = d_ptr; a.indptr64 = indptr_is_64; a.indices = d_idx; a.data = d_val; a.perm = L.perm;
+    a.n = n_rows; a.row0 = L.row0; a.nloc = L.nloc; a.lead = L.g.lead; a.xlen = L.xlen; a.prune = prune_zeros;
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->partials);
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(csr_scan, dim3(blocks_for(n_rows, 256)), dim3(256), 0, c->stream, a, d_stats);
+    unsigned long long stats[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats[2] & 1ull) { cleanup(); return fail("a matrix row couples unknowns more than one grid plane apart (not a slab-local stencil)"); }
+    if (stats[2] & 2ull) { cleanup(); return fail("a matrix row has a zero or missing diagonal"); }
+    L.W = (int)std::max<unsigned long long>(1, stats[0]);
+    L.nnz_stored = stats[1];
+    if (int r = alloc_ell(c, L)) { cleanup(); return r; }
+    const dim3 g1(blocks_for(n_rows, 256)), b1(256);
+    switch (L.R) {
+        case 1: hipLaunchKernelGGL(csr_to_ell<1>, g1, b1, 0, c->stream, a, L.vals, L.cols, L.dinv, L.W); break;
+        case 2: hipLaunchKernelGGL(csr_to_ell<2>, g1, b1, 0, c->stream, a, L.vals, L.cols, L.dinv, L.W); break;
+        default: hipLaunchKernelGGL(csr_to_ell<4>, g1, b1, 0, c->stream, a, L.vals, L.cols, L.dinv, L.W); break;
+    }
+    HIP_TRY(hipGetLastError());
+    // true non-zeros among the kept entries (== kept when pruned)
+    if (prune_zeros) {
+        L.nnz_nonzero = L.nnz_stored;
+    } else {
+        unsigned long long nz = 0;
+        // count on the host copy the caller still owns (set-up only)
+        if (!c->comm.active() || L.replicated) {
+            for (int64_t q = 0; q < nnz; ++q) nz += data[q] != 0.0;
+        } else {
+            nz = L.nnz_stored;
+        }
+        L.nnz_nonzero = nz;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    cleanup();
+    L.has_matrix = true;
+    return finish_level(c, L);
+}
+
+int mg_set_level_grid(mg_handle c, int level, int N, int64_t n_rows, const int64_t* grid_index) {
+    MG_TRY(check_level(c, level, false));
+    if (N < 0) return fail("elements_per_dim must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, level, N, n_rows));
+    if (n_rows != L.n_global)
+        return fail("vector has " + std::to_string(n_rows) + " entries, grid has " + std::to_string(L.n_global));
+    if (grid_index) {
+        std::vector<int> p32((size_t)n_rows);
+        std::vector<char> seen((size_t)n_rows, 0);
+        for (int64_t d = 0; d < n_rows; ++d) {
+            const int64_t p = grid_index[d];
+            if (p < 0 || p >= n_rows || seen[(size_t)p]) return fail("grid_index is not a permutation of the grid nodes");
+            seen[(size_t)p] = 1;
+            p32[(size_t)d] = (int)p;
+        }
+        MG_TRY(dev_alloc(c, &L.perm, (size_t)n_rows));
+        HIP_TRY(hipMemcpy(L.perm, p32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    }
+    return finish_level(c, L);
+}
+
+int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
+    MG_TRY(check_level(c, level, false));
+    if (N <= 0) return fail("elements_per_dim must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, level, N));
+    GenArgs a{};
+    a.g = L.g; a.N = N; a.dim = c->dim; a.prune = prune_zeros;
+    a.h = 1.0 / (double)N;
+    a.w = c->dim == 2 ? 1.0 : a.h;
+    a.diag = c->dim == 2 ? 4.0 : 6.0 * a.h;
+    a.fh = (c->dim == 2 ? -6.0 : -12.0) * std::pow(a.h, (double)c->dim);
+    sorted_offsets(c->dim, a.off, &a.noff);
+    L.W = prune_zeros ? (c->dim == 2 ? 5 : 7) : a.noff;
+    a.W = L.W;
+    MG_TRY(alloc_ell(c, L));
+    MG_TRY(alloc_level_vectors(c, L));
+    unsigned long long* d_counts = reinterpret_cast<unsigned long long*>(c->partials);
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), c->stream));
+    const dim3 grid = grid3(L.g, L.g.nk), blk(128);
+    switch (L.R) {
+        case 1: hipLaunchKernelGGL(gen_poisson<1>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+        case 2: hipLaunchKernelGGL(gen_poisson<2>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+        default: hipLaunchKernelGGL(gen_poisson<4>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long counts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    L.nnz_stored = counts[0];
+    L.nnz_nonzero = counts[1];
+    // the generated right-hand side is also this level's true right-hand side for mg_fmg
+    if (level + 1 < c->nlev) {
+        MG_TRY(vec_alloc(c, L, &L.ftrue));
+        HIP_TRY(hipMemcpyAsync(L.ftrue.base, L.f.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    L.set = true;
+    L.has_matrix = true;
+    return 0;
+}
+
+int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                    const int32_t* indices, const double* data, double* dinv, double* scaled, unsigned char* keep) {
+    if (!indptr || !indices || !data || !dinv || !scaled || !keep) return fail("null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("no HIP device visible: this library has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    void* d_ptr = nullptr;
+    int* d_idx = nullptr;
+    double *d_val = nullptr, *d_dinv = nullptr, *d_scaled = nullptr;
+    unsigned char* d_keep = nullptr;
+    const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
+    const size_t nz = std::max<size_t>(1, (size_t)nnz);
+    auto cleanup = [&]() {
+        (void)hipFree(d_ptr); (void)hipFree(d_idx); (void)hipFree(d_val);
+        (void)hipFree(d_dinv); (void)hipFree(d_scaled); (void)hipFree(d_keep);
+    };
+    int rc = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_ptr, ptr_bytes));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), nz * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_val), nz * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dinv), std::max<size_t>(1, (size_t)n_rows) * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_scaled), nz * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_keep), nz));
+        HIP_TRY(hipMemcpy(d_ptr, indptr, ptr_bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_idx, indices, (size_t)nnz * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_val, data, (size_t)nnz * 8, hipMemcpyHostToDevice));
+        CsrArgs a{};
+        a.indptr = d_ptr; a.indptr64 = indptr_is_64; a.indices = d_idx; a.data = d_val; a.n = n_rows;
+        hipLaunchKernelGGL(jacobi_split, dim3(blocks_for(n_rows, 256)), dim3(256), 0, 0, a, d_dinv, d_scaled, d_keep);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(dinv, d_dinv, (size_t)n_rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(scaled, d_scaled, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(keep, d_keep, (size_t)nnz, hipMemcpyDeviceToHost));
+        return 0;
+    }();
+    cleanup();
+    return rc;
+}
+
+int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, int64_t* row0, int64_t* nnz_stored,
+                  int64_t* nnz_nonzero, int* ell_width, int* replicated) {
+    MG_TRY(check_level(c, level));
+    const Level& L = c->L[level];
+    if (n_global) *n_global = L.n_global;
+    if (n_local) *n_local = L.nloc;
+    if (row0) *row0 = L.row0;
+    if (nnz_stored) *nnz_stored = (int64_t)L.nnz_stored;
+    if (nnz_nonzero) *nnz_nonzero = (int64_t)L.nnz_nonzero;
+    if (ell_width) *ell_width = L.W;
+    if (replicated) *replicated = L.replicated ? 1 : 0;
+    return 0;
+}
+
+int mg_set_vector(mg_handle c, int level, int which, const double* host) {
+    MG_TRY(check_level(c, level));
+    if (!host) return fail("null host vector");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    DVector* v = pick(L, which);
+    if (!v) return fail("unknown vector selector");
+    MG_TRY(vec_alloc(c, L, v));
+    return upload_vector(c, L, *v, host);
+}
+
+int mg_set_rhs_true(mg_handle c, int level, const double* host) {
+    MG_TRY(check_level(c, level));
+    if (!host) return fail("null host vector");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    MG_TRY(vec_alloc(c, L, &L.ftrue));
+    return upload_vector(c, L, L.ftrue, host);
+}
+
+int mg_get_vector(mg_handle c, int level, int which, double* host, int gather) {
+    MG_TRY(check_level(c, level));
+    if (!host) return fail("null host vector");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    DVector* v = pick(L, which);
+    if (!v || !v->raw) return fail("vector is not available on this level");
+    MG_TRY(ensure_stage(c, L.n_global));
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (L.n_global + 255) / 256);
+    if (gather && !L.replicated && c->comm.active()) {
+        // all-gather slabs in lexicographic order inside a scratch vector, then permute
+        double* full = nullptr;
+        MG_TRY(dev_alloc(c, &full, (size_t)L.n_global));
+        HIP_TRY(hipMemcpyAsync(full + L.row0, v->rows, (size_t)L.nloc * 8, hipMemcpyDeviceToDevice, c->stream));
+        int rc = allgather_planes(c, L.splits, L.g.plane, full);
+        if (!rc) {
+            hipLaunchKernelGGL(gather_out, dim3(nb), dim3(256), 0, c->stream, full, L.perm, L.n_global, (int64_t)0,
+                               L.n_global, (int64_t)0, c->stage);
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        dev_free(c, full, (size_t)L.n_global);
+        if (rc) return rc;
+        HIP_TRY(e);
+        HIP_TRY(hipMemcpy(host, c->stage, (size_t)L.n_global * 8, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (!L.replicated && c->comm.active()) {
+        // owned rows only: pre-load the caller's buffer so untouched entries survive
+        HIP_TRY(hipMemcpyAsync(c->stage, host, (size_t)L.n_global * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(gather_out, dim3(nb), dim3(256), 0, c->stream, v->base, L.perm, L.n_global, L.row0, L.nloc,
+                       L.g.lead, c->stage);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, c->stage, (size_t)L.n_global * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mg_zero_vector(mg_handle c, int level, int which) {
+    MG_TRY(check_level(c, level));
+    Level& L = c->L[level];
+    DVector* v = pick(L, which);
+    if (!v) return fail("unknown vector selector");
+    MG_TRY(vec_alloc(c, L, v));
+    return zero_vec(c, L, *v);
+}
+
+int mg_copy_vector(mg_handle c, int level, int dst_which, int src_which) {
+    MG_TRY(check_level(c, level));
+    Level& L = c->L[level];
+    DVector* d = pick(L, dst_which);
+    DVector* s = pick(L, src_which);
+    if (!d || !s || !s->raw) return fail("bad vector selector");
+    MG_TRY(vec_alloc(c, L, d));
+    if (d->raw == s->raw) return 0;
+    HIP_TRY(hipMemcpyAsync(d->base, s->base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int mg_smooth(mg_handle c, int level, int nw) {
+    MG_TRY(need_matrix(c, level));
+    if (nw < 0) return fail("nw must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    MG_TRY(exchange_halo(c, c->L[level], c->L[level].v));
+    return smooth(c, level, nw);
+}
+
+int mg_residual(mg_handle c, int level) {
+    MG_TRY(need_matrix(c, level));
+    HIP_TRY(hipSetDevice(c->device));
+    MG_TRY(exchange_halo(c, c->L[level], c->L[level].v));
+    return residual(c, level);
+}
+
+int mg_restrict(mg_handle c, int level, int kind) {
+    MG_TRY(check_level(c, level));
+    if (level == 0) return fail("level 0 has no coarser level");
+    MG_TRY(need_grid(c, level));
+    MG_TRY(need_grid(c, level - 1));
+    if (kind != MG_RESTRICT_INJECTION && kind != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
+    HIP_TRY(hipSetDevice(c->device));
+    return restrict_to(c, level, kind);
+}
+
+int mg_prolong(mg_handle c, int level, int add) {
+    MG_TRY(check_level(c, level));
+    if (level == 0) return fail("level 0 has no coarser level");
+    MG_TRY(need_grid(c, level));
+    MG_TRY(need_grid(c, level - 1));
+    HIP_TRY(hipSetDevice(c->device));
+    MG_TRY(exchange_halo(c, c->L[level - 1], c->L[level - 1].v));
+    return prolong(c, level, add);
+}
+
+int mg_coarse_solve(mg_handle c, int* iterations, double* rel_residual) {
+    MG_TRY(need_matrix(c, 0));
+    HIP_TRY(hipSetDevice(c->device));
+    return coarse_solve(c, iterations, rel_residual);
+}
+
+int mg_norm2(mg_handle c, int level, int which, double* out) {
+    MG_TRY(check_level(c, level));
+    if (!out) return fail("null output");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    DVector* v = pick(L, which);
+    if (!v || !v->raw) return fail("vector is not available on this level");
+    return norm2(c, L, v->rows, out);
+}
+
+int mg_quadratic_form(mg_handle c, int level, int which, double* out) {
+    MG_TRY(need_matrix(c, level));
+    if (!out) return fail("null output");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    DVector* v = pick(L, which);
+    if (!v || !v->raw || v == &L.v2) return fail("vector is not available for a quadratic form");
+    MG_TRY(exchange_halo(c, L, *v));
+    const unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
+    double* parts = nullptr;
+    MG_TRY(dev_alloc(c, &parts, grid));
+    int rc = launch_ell(c, L, MODE_SPMV, true, v->base, nullptr, L.v2.rows, parts, nullptr);
+    if (!rc) {
+        hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(BLOCK), 0, c->stream, parts, (int)grid, c->scalars);
+        if (!L.replicated) rc = allreduce_sum(c, c->scalars, 1);
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(c->h_scalars, c->scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(hipGetErrorString(e));
+    }
+    dev_free(c, parts, grid);
+    if (rc) return rc;
+    *out = c->h_scalars[0];
+    return 0;
+}
+
+int mg_vcycle(mg_handle c, int level, int ncycles, double* resid_l2) {
+    MG_TRY(check_level(c, level));
+    for (int l = 0; l <= level; ++l) {
+        MG_TRY(need_matrix(c, l));
+        if (level > 0) MG_TRY(need_grid(c, l));
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    MG_TRY(exchange_halo(c, L, L.v));
+    for (int k = 0; k < ncycles; ++k) {
+        MG_TRY(vcycle(c, level));
+        if (resid_l2) {
+            MG_TRY(residual(c, level));
+            MG_TRY(norm2(c, L, L.v2.rows, &resid_l2[k]));
+        }
+    }
+    return 0;
+}
+
+int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* resid_l2, int* cycles_done) {
+    MG_TRY(check_level(c, top));
+    for (int l = 0; l <= top; ++l) {
+        MG_TRY(need_matrix(c, l));
+        if (top > 0) MG_TRY(need_grid(c, l));
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    for (int l = 0; l < top; ++l) {
+        Level& L = c->L[l];
+        if (!L.ftrue.raw) return fail("mg_fmg needs the true right-hand side of level " + std::to_string(l));
+        HIP_TRY(hipMemcpyAsync(L.f.base, L.ftrue.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    MG_TRY(coarse_solve(c, nullptr, nullptr));
+    int done_cycles = 0;
+    for (int l = 1; l <= top; ++l) {
+        Level& L = c->L[l];
+        if (l < top)   // cycles on level l-1 consumed F[l-1..0]; F[l] is still the true right-hand side
+            HIP_TRY(hipMemcpyAsync(L.f.base, L.ftrue.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+        // v_h = Interpolation(v_2h) (multigrid.py:283-284): interpolate into ERR, then copy to V
+        MG_TRY(exchange_halo(c, c->L[l - 1], c->L[l - 1].v));
+        MG_TRY(prolong(c, l, 0));
+        HIP_TRY(hipMemcpyAsync(L.v.base, L.err.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+        MG_TRY(exchange_halo(c, L, L.v));
+        if (l < top || tol <= 0.0) {
+            for (int k = 0; k < mu0; ++k) {
+                MG_TRY(vcycle(c, l));
+                if (l == top) {
+                    ++done_cycles;
+                    if (resid_l2) {
+                        MG_TRY(residual(c, l));
+                        MG_TRY(norm2(c, L, L.v2.rows, &resid_l2[k]));
+                    }
+                }
+            }
+        } else {
+            for (int k = 0; k < max_cycles; ++k) {
+                MG_TRY(vcycle(c, l));
+                ++done_cycles;
+                MG_TRY(residual(c, l));
+                double rn = 0.0;
+                MG_TRY(norm2(c, L, L.v2.rows, &rn));
+                if (resid_l2) resid_l2[k] = rn;
+                if (rn <= tol) break;
+            }
+        }
+    }
+    if (cycles_done) *cycles_done = done_cycles;
+    return 0;
+}
+
+int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double* avg_ms) {
+    MG_TRY(need_matrix(c, level));
+    if (!kernel || !avg_ms || reps < 1) return fail("bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const std::string k(kernel);
+    Level& L = c->L[level];
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto once = [&]() -> int {
+        if (k == "jacobi") return launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
+        if (k == "residual") return residual(c, level);
+        if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");
+        if (k == "prolong") return level > 0 ? prolong(c, level, 1) : fail("level 0");
+        if (k == "norm2") return dot_device(c, L, L.v.rows, L.v.rows, 1);
+        return fail("unknown kernel " + k);
+    };
+    MG_TRY(once());   // warm-up
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) MG_TRY(once());
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    return 0;
+}
+
+int mg_sync(mg_handle c) {
+    if (!c) return fail("null handle");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mg_memory_bytes(mg_handle c, int64_t* bytes) {
+    if (!c || !bytes) return fail("bad arguments");
+    *bytes = c->bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,586 @@
+// Device kernels of the V-cycle hot path for gfx950 (CDNA4, wave64).
+//
+// All of these are HBM-bound sparse applies / gathers at <= 0.17 flop/byte, so there is
+// no MFMA here: the levers are coalesced 8-16 B/lane tile loads, enough bytes in flight
+// per CU, x-vector reuse through L1/L2/MALL and an XCD-aware block -> tile map.
+//
+// Data layout ("sliced ELL", one slice = 64*R consecutive lexicographic rows, one wave per
+// slice, lane l owns rows l*R .. l*R+R-1 of the slice):
+//     vals[((slice*W + k)*64 + lane)*R + r]     fp64   k-th stored entry of that row
+//     cols[  same index                   ]     int32  its column, as an index into the
+//                                                       local vector (halo planes included)
+// so a wave reads W contiguous runs of 64*R*8 B (values) and 64*R*4 B (columns): every
+// load instruction is a fully coalesced 8*R / 4*R bytes per lane.  Padding entries carry
+// value 0.0 and the row's own column.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgk {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;          // 4 waves
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+template <int R> struct alignas(8 * R) DVec { double d[R]; };
+template <int R> struct alignas(4 * R) IVec { int d[R]; };
+
+enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
+
+// Geometry of one level's (slab of the) grid.  2-D grids are stored as (nx, 1, nz).
+struct Grid {
+    int nx, ny, nz;          // global nodes per axis (ny == 1 in 2-D)
+    int k0, nk;              // owned planes [k0, k0+nk) along z (the slab axis)
+    int64_t plane;           // nx*ny
+    int64_t lead;            // elements in front of the first owned row (lower halo plane or 0)
+    int refine_y;            // 1 if the y axis takes part in coarsening (3-D)
+};
+
+// ---- XCD-aware block -> tile map ------------------------------------------------------
+// Blocks are dealt round-robin over the 8 XCDs (b % 8 says which blocks share an L2).
+// With chunk c > 1, each XCD works on c consecutive tiles at a time, so lines of the
+// source vector fetched for one grid row are re-used from the same L2 by the rows next
+// to it, while all XCDs still advance through the vector together (which keeps the
+// plane-distance re-reads inside the 256 MiB memory-side cache).  Speed only.
+__device__ __forceinline__ unsigned swizzle_block(unsigned b, unsigned nb, unsigned chunk) {
+    if (chunk <= 1) return b;
+    const unsigned group = 8u * chunk;
+    const unsigned full = (nb / group) * group;
+    if (b >= full) return b;
+    const unsigned g = b / group, in = b % group;
+    const unsigned xcd = in % 8u, idx = in / 8u;
+    return g * group + xcd * chunk + idx;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum, result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v) {
+    __shared__ double s_part[WAVES_PER_BLOCK];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_part[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += s_part[w];
+    }
+    return t;
+}
+
+struct EllArgs {
+    const double* vals;
+    const int* cols;
+    const double* x;        // source vector, base of storage (cols index into it)
+    const double* f;        // right-hand side, row-based (already offset by lead)
+    const double* dinv;     // 1/diag, row-based
+    double* out;            // row-based
+    double* partials;       // per-block partial dot (MODE_SPMV with DOT)
+    const int* done_flag;   // optional early-exit flag (coarse solver)
+    int64_t nloc;           // owned rows
+    int64_t lead;           // x[lead + row] is the row's own entry
+    int64_t slice0, nslices;  // slices [slice0, slice0 + nslices) are processed
+    double omega;
+    int W;                  // runtime width (used when the template width is 0)
+    unsigned chunk;
+};
+
+// One wave = one slice.  MODE_RESIDUAL: out = f - A x.  MODE_JACOBI: out = x + w D^-1 (f - A x)
+// (jacobiRelaxation, multigrid.py:226, in the algebraically identical one-matrix form).
+// MODE_SPMV: out = A x, with DOT also partial sums of x . (A x).
+template <int WT, int R, int MODE, bool DOT>
+__global__ __launch_bounds__(BLOCK) void ell_apply(EllArgs a) {
+    if (a.done_flag && *a.done_flag) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const unsigned b = swizzle_block(blockIdx.x, gridDim.x, a.chunk);
+    const int64_t sl = (int64_t)b * WAVES_PER_BLOCK + wave;
+    double dot = 0.0;
+    if (sl < a.nslices) {
+        const int64_t slice = a.slice0 + sl;
+        const int W = WT > 0 ? WT : a.W;
+        const size_t base = (size_t)slice * (size_t)W * (WAVE * R) + (size_t)lane * R;
+        const int64_t row = slice * (WAVE * R) + (int64_t)lane * R;
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        if (WT > 0) {
+            DVec<R> v[WT > 0 ? WT : 1];
+            IVec<R> c[WT > 0 ? WT : 1];
+#pragma unroll
+            for (int k = 0; k < WT; ++k) {
+                c[k] = *reinterpret_cast<const IVec<R>*>(a.cols + base + (size_t)k * (WAVE * R));
+                v[k] = *reinterpret_cast<const DVec<R>*>(a.vals + base + (size_t)k * (WAVE * R));
+            }
+#pragma unroll
+            for (int k = 0; k < WT; ++k) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fma(v[k].d[r], a.x[c[k].d[r]], acc[r]);
+            }
+        } else {
+            for (int k = 0; k < W; ++k) {
+                const IVec<R> c = *reinterpret_cast<const IVec<R>*>(a.cols + base + (size_t)k * (WAVE * R));
+                const DVec<R> v = *reinterpret_cast<const DVec<R>*>(a.vals + base + (size_t)k * (WAVE * R));
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fma(v.d[r], a.x[c.d[r]], acc[r]);
+            }
+        }
+        DVec<R> o;
+        if (row + R <= a.nloc) {
+            if (MODE == MODE_SPMV) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) o.d[r] = acc[r];
+                if (DOT) {
+                    const DVec<R> xr = *reinterpret_cast<const DVec<R>*>(a.x + a.lead + row);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dot += xr.d[r] * acc[r];
+                }
+            } else {
+                const DVec<R> fr = *reinterpret_cast<const DVec<R>*>(a.f + row);
+                if (MODE == MODE_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) o.d[r] = fr.d[r] - acc[r];
+                } else {
+                    const DVec<R> xr = *reinterpret_cast<const DVec<R>*>(a.x + a.lead + row);
+                    const DVec<R> di = *reinterpret_cast<const DVec<R>*>(a.dinv + row);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) o.d[r] = xr.d[r] + (a.omega * di.d[r]) * (fr.d[r] - acc[r]);
+                }
+            }
+            *reinterpret_cast<DVec<R>*>(a.out + row) = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t rr = row + r;
+                if (rr < a.nloc) {
+                    double val;
+                    if (MODE == MODE_SPMV) {
+                        val = acc[r];
+                        if (DOT) dot += a.x[a.lead + rr] * acc[r];
+                    } else if (MODE == MODE_RESIDUAL) {
+                        val = a.f[rr] - acc[r];
+                    } else {
+                        val = a.x[a.lead + rr] + (a.omega * a.dinv[rr]) * (a.f[rr] - acc[r]);
+                    }
+                    a.out[rr] = val;
+                }
+            }
+        }
+    }
+    if (DOT) {
+        const double t = block_sum(dot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+    }
+}
+
+// ---- CSR hand-off -> sliced ELL ----------------------------------------------------------
+struct CsrArgs {
+    const void* indptr;      // int32 or int64
+    int indptr64;
+    const int* indices;
+    const double* data;
+    const int* perm;         // dof -> global lexicographic node, or null
+    int64_t n;               // global rows
+    int64_t row0, nloc;      // owned global rows [row0, row0+nloc)
+    int64_t lead, xlen;      // local vector = [lead | nloc | upper halo], xlen total
+    int prune;
+};
+
+__device__ __forceinline__ int64_t csr_ptr(const CsrArgs& a, int64_t i) {
+    return a.indptr64 ? reinterpret_cast<const int64_t*>(a.indptr)[i]
+                      : (int64_t) reinterpret_cast<const int*>(a.indptr)[i];
+}
+
+// Pass 1: widest kept row among owned rows, number of kept entries, sanity flags.
+// stats[0] = max width, stats[1] = kept entries, stats[2] = error bits
+// (1: column outside the slab's reach, 2: zero/missing diagonal).
+__global__ void csr_scan(CsrArgs a, unsigned long long* stats) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.n) return;
+    const int64_t p = a.perm ? a.perm[d] : d;
+    const int64_t lr = p - a.row0;
+    if (lr < 0 || lr >= a.nloc) return;
+    const int64_t b = csr_ptr(a, d), e = csr_ptr(a, d + 1);
+    unsigned kept = 0, err = 0;
+    bool diag = false;
+    for (int64_t q = b; q < e; ++q) {
+        const double v = a.data[q];
+        const int64_t cp = a.perm ? a.perm[a.indices[q]] : a.indices[q];
+        if (cp == p && v != 0.0) diag = true;
+        if (a.prune && v == 0.0) continue;
+        const int64_t lc = cp - a.row0 + a.lead;
+        if (lc < 0 || lc >= a.xlen) err |= 1u;
+        ++kept;
+    }
+    if (!diag) err |= 2u;
+    atomicMax(&stats[0], (unsigned long long)kept);
+    atomicAdd(&stats[1], (unsigned long long)kept);
+    if (err) atomicOr(&stats[2], (unsigned long long)err);
+}
+
+// Pass 0: every slot = (0.0, own column); rows past nloc point at a valid element.
+template <int R>
+__global__ void ell_fill_padding(double* vals, int* cols, int64_t nslices, int W, int64_t nloc, int64_t lead) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nslices * W * (WAVE * R);
+    if (t >= total) return;
+    const int64_t per_slice = (int64_t)W * (WAVE * R);
+    const int64_t slice = t / per_slice;
+    const int64_t in = t % per_slice;
+    const int64_t within = in % (WAVE * R);          // lane*R + r
+    int64_t row = slice * (WAVE * R) + within;
+    if (row >= nloc) row = nloc - 1;
+    vals[t] = 0.0;
+    cols[t] = (int)(lead + row);
+}
+
+// Pass 2: scatter kept entries in stored order; D^-1.
+template <int R>
+__global__ void csr_to_ell(CsrArgs a, double* vals, int* cols, double* dinv, int W) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.n) return;
+    const int64_t p = a.perm ? a.perm[d] : d;
+    const int64_t lr = p - a.row0;
+    if (lr < 0 || lr >= a.nloc) return;
+    const int64_t slice = lr / (WAVE * R);
+    const int64_t within = lr % (WAVE * R);
+    const size_t base = (size_t)slice * W * (WAVE * R) + within;
+    const int64_t b = csr_ptr(a, d), e = csr_ptr(a, d + 1);
+    int k = 0;
+    double diag = 1.0;
+    for (int64_t q = b; q < e; ++q) {
+        const double v = a.data[q];
+        const int64_t cp = a.perm ? a.perm[a.indices[q]] : a.indices[q];
+        if (cp == p && v != 0.0) diag = v;
+        if (a.prune && v == 0.0) continue;
+        if (k < W) {
+            vals[base + (size_t)k * (WAVE * R)] = v;
+            cols[base + (size_t)k * (WAVE * R)] = (int)(cp - a.row0 + a.lead);
+        }
+        ++k;
+    }
+    dinv[lr] = 1.0 / diag;
+}
+
+// getJacobiMatrices (multigrid.py:48-56): D^-1 and the entries of D^-1 (A - D), in place of
+// SciPy's diagonal(), CSR - DIA and DIA . CSR.  One row per thread (set-up, once per level).
+__global__ void jacobi_split(CsrArgs a, double* dinv, double* scaled, unsigned char* keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t b = csr_ptr(a, i), e = csr_ptr(a, i + 1);
+    double diag = 0.0;
+    for (int64_t q = b; q < e; ++q)
+        if (a.indices[q] == i) diag += a.data[q];          // duplicates sum, as A.diagonal() does
+    const double di = 1.0 / diag;
+    dinv[i] = di;
+    for (int64_t q = b; q < e; ++q) {
+        const double v = a.data[q];
+        const bool on_diag = a.indices[q] == i;
+        scaled[q] = di * v;
+        keep[q] = (!on_diag && v != 0.0) ? 1 : 0;
+    }
+}
+
+// ---- synthetic P1 Poisson level, written straight into tiles --------------------------------
+// Same entries, in the same order, as poisson.lexicographic_level + csr_to_ell give.
+struct GenArgs {
+    Grid g;
+    int N;              // elements per dimension
+    int dim;
+    int prune;
+    int W;
+    double h, w, diag, fh;   // h = 1/N, axis coupling magnitude, interior diagonal, f*h^dim
+    int noff;
+    int off[15][3];     // sorted pattern offsets (di, dj, dk) in unified (x, y, z) axes
+};
+
+__device__ __forceinline__ double gen_g(const GenArgs& a, int i, int j, int k) {
+    const double x = (double)i / (double)a.N;
+    if (a.dim == 2) {
+        const double y = (double)k / (double)a.N;      // 2-D grids use the z axis for y
+        return 1.0 + x * x + 2.0 * (y * y);
+    }
+    const double y = (double)j / (double)a.N;
+    const double z = (double)k / (double)a.N;
+    return 1.0 + x * x + 2.0 * (y * y) + 3.0 * (z * z);
+}
+
+__device__ __forceinline__ bool gen_on_boundary(const GenArgs& a, int i, int j, int k) {
+    bool bnd = (i == 0) || (i == a.g.nx - 1) || (k == 0) || (k == a.g.nz - 1);
+    if (a.dim == 3) bnd = bnd || (j == 0) || (j == a.g.ny - 1);
+    return bnd;
+}
+
+template <int R>
+__global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, double* f,
+                            unsigned long long* counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int kl = blockIdx.z;              // local plane
+    unsigned nz = 0, kept = 0;
+    if (i < a.g.nx) {
+        const int k = a.g.k0 + kl;
+        const int64_t lr = (int64_t)kl * a.g.plane + (int64_t)j * a.g.nx + i;
+        const int64_t slice = lr / (WAVE * R);
+        const int64_t within = lr % (WAVE * R);
+        const size_t base = (size_t)slice * a.W * (WAVE * R) + within;
+        const bool bnd = gen_on_boundary(a, i, j, k);
+        double b = bnd ? gen_g(a, i, j, k) : a.fh;
+        for (int t = 0; t < a.noff; ++t) {
+            const int di = a.off[t][0], dj = a.off[t][1], dk = a.off[t][2];
+            const int ii = i + di, jj = j + dj, kk = k + dk;
+            if (ii < 0 || ii >= a.g.nx || jj < 0 || jj >= a.g.ny || kk < 0 || kk >= a.g.nz) continue;
+            const int naxis = (di != 0) + (dj != 0) + (dk != 0);
+            double v;
+            if (naxis == 0) {
+                v = bnd ? 1.0 : a.diag;
+            } else if (naxis == 1) {
+                const bool nb = gen_on_boundary(a, ii, jj, kk);
+                v = (!bnd && !nb) ? -a.w : 0.0;
+                if (!bnd && nb) b = b + a.w * gen_g(a, ii, jj, kk);
+            } else {
+                v = 0.0;
+            }
+            if (v != 0.0) ++nz;
+            if (a.prune && v == 0.0) continue;
+            const int64_t lc = a.g.lead + lr + (int64_t)dk * a.g.plane + (int64_t)dj * a.g.nx + di;
+            if ((int)kept < a.W) {
+                vals[base + (size_t)kept * (WAVE * R)] = v;
+                cols[base + (size_t)kept * (WAVE * R)] = (int)lc;
+            }
+            ++kept;
+        }
+        dinv[lr] = 1.0 / (bnd ? 1.0 : a.diag);
+        f[lr] = b;
+    }
+    // one atomic pair per wave; counts[0] = stored entries, counts[1] = non-zero entries
+    const unsigned ksum = (unsigned)wave_sum((double)kept);
+    const unsigned zsum = (unsigned)wave_sum((double)nz);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)ksum);
+        atomicAdd(&counts[1], (unsigned long long)zsum);
+    }
+}
+
+// ---- grid transfers (lexicographic index arithmetic; no coordinate hashing) ---------------------
+// Injection (Restriction2D_direct, multigrid.py:123-132): coarse (I,J,K) <- fine (2I,2J,2K).
+__global__ void restrict_inject(Grid gc, Grid gf, const double* __restrict__ rf, double* __restrict__ fc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int kl = blockIdx.z;
+    if (i >= gc.nx) return;
+    const int kf = 2 * (gc.k0 + kl) - gf.k0;                 // local fine plane
+    const int jf = gf.refine_y ? 2 * j : j;
+    const int64_t src = gf.lead + (int64_t)kf * gf.plane + (int64_t)jf * gf.nx + 2 * i;
+    fc[gc.lead + (int64_t)kl * gc.plane + (int64_t)j * gc.nx + i] = rf[src];
+}
+
+// Full weighting (Restriction2D, multigrid.py:135-198); neighbours outside the grid are skipped
+// (:172-194).  2-D: (1/16)(corners + 2 edges + 4 centre) in the reference's summation order;
+// 3-D (no reference): (1/64)(corners + 2 edges + 4 faces + 8 centre).  Needs valid fine halos.
+__global__ void restrict_full_weighting(Grid gc, Grid gf, const double* __restrict__ rf, double* __restrict__ fc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int kl = blockIdx.z;
+    if (i >= gc.nx) return;
+    const int K = gc.k0 + kl;
+    const int fi = 2 * i, fk = 2 * K;
+    auto at = [&](int di, int dj, int dk, double& acc) {
+        const int ii = fi + di, kk = fk + dk;
+        const int jj = (gf.refine_y ? 2 * j : j) + dj;
+        if (ii < 0 || ii >= gf.nx || jj < 0 || jj >= gf.ny || kk < 0 || kk >= gf.nz) return;
+        acc = acc + rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii];
+    };
+    double out;
+    if (!gf.refine_y) {
+        // reference tuples are (x, y) = (i, k here)
+        double s1 = 0.0, s2 = 0.0, c = 0.0;
+        at(-1, 0, -1, s1); at(-1, 0, 1, s1); at(1, 0, -1, s1); at(1, 0, 1, s1);
+        at(0, 0, -1, s2); at(0, 0, 1, s2); at(-1, 0, 0, s2); at(1, 0, 0, s2);
+        at(0, 0, 0, c);
+        out = (1.0 / 16.0) * (s1 + 2.0 * s2 + 4.0 * c);
+    } else {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int dk = -1; dk <= 1; ++dk)
+            for (int dj = -1; dj <= 1; ++dj)
+                for (int di = -1; di <= 1; ++di) {
+                    const int m = (di != 0) + (dj != 0) + (dk != 0);
+                    at(di, dj, dk, s[m]);
+                }
+        out = (1.0 / 64.0) * (s[3] + 2.0 * s[2] + 4.0 * s[1] + 8.0 * s[0]);
+    }
+    fc[gc.lead + (int64_t)kl * gc.plane + (int64_t)j * gc.nx + i] = out;
+}
+
+// Q1 prolongation + correction (Interpolation2D, multigrid.py:59-120, and `v_h + err_h`, :260):
+// coincident nodes copy, edge nodes 0.5*(a+b), face/cell centres 0.25*(..)/0.125*(..), summed
+// x-neighbour first as the reference does.  err (optional) receives the interpolated values.
+template <bool ADD, bool KEEP>
+__global__ void prolong_correct(Grid gc, Grid gf, const double* __restrict__ vc, double* __restrict__ vf,
+                                double* __restrict__ err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int kl = blockIdx.z;
+    if (i >= gf.nx) return;
+    const int k = gf.k0 + kl;
+    const int pi = i & 1, pk = k & 1;
+    const int pj = gf.refine_y ? (j & 1) : 0;
+    const int ic = i >> 1, kc = (k >> 1) - gc.k0;
+    const int jc = gf.refine_y ? (j >> 1) : j;
+    const double* base = vc + gc.lead + (int64_t)kc * gc.plane + (int64_t)jc * gc.nx + ic;
+    double s = 0.0;
+    bool first = true;
+    for (int dk = 0; dk <= pk; ++dk)
+        for (int dj = 0; dj <= pj; ++dj)
+            for (int di = 0; di <= pi; ++di) {
+                const double c = base[(int64_t)dk * gc.plane + (int64_t)dj * gc.nx + di];
+                s = first ? c : s + c;
+                first = false;
+            }
+    const int cnt = 1 << (pi + pj + pk);
+    const double e = cnt == 1 ? s : (1.0 / (double)cnt) * s;
+    const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + i;
+    if (KEEP) err[o] = e;
+    if (ADD) vf[o] = vf[o] + e;
+}
+
+// ---- vector utilities ---------------------------------------------------------------------------
+__global__ void fill_zero(double* x, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        x[t] = 0.0;
+}
+
+// caller numbering -> local lexicographic storage (owned rows and halo planes)
+__global__ void scatter_in(const double* __restrict__ in, const int* __restrict__ perm, int64_t n,
+                           int64_t row0, int64_t lead, int64_t xlen, double* __restrict__ x) {
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = perm ? perm[d] : d;
+        const int64_t l = p - row0 + lead;
+        if (l >= 0 && l < xlen) x[l] = in[d];
+    }
+}
+
+// local lexicographic storage (owned rows) -> caller numbering
+__global__ void gather_out(const double* __restrict__ x, const int* __restrict__ perm, int64_t n,
+                           int64_t row0, int64_t nloc, int64_t lead, double* __restrict__ out) {
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = perm ? perm[d] : d;
+        const int64_t l = p - row0;
+        if (l >= 0 && l < nloc) out[d] = x[lead + l];
+    }
+}
+
+// partial sums of x.y over n entries -> partials[blockIdx]; deterministic (no atomics)
+__global__ __launch_bounds__(BLOCK) void dot_partial(const double* __restrict__ x, const double* __restrict__ y,
+                                                      int64_t n, double* __restrict__ partials) {
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // two doubles per lane per step where alignment allows
+    for (; t * 2 + 1 < n; t += stride) {
+        const double2 a = reinterpret_cast<const double2*>(x)[t];
+        const double2 b = reinterpret_cast<const double2*>(y)[t];
+        s = fma(a.x, b.x, s);
+        s = fma(a.y, b.y, s);
+    }
+    if (t * 2 < n && t * 2 + 1 >= n) s = fma(x[t * 2], y[t * 2], s);
+    const double r = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// out[0] = sum(partials[0..np))
+__global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int np, double* out) {
+    double s = 0.0;
+    for (int t = threadIdx.x; t < np; t += blockDim.x) s += partials[t];
+    const double r = block_sum(s);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+// ---- coarsest-level solver: Jacobi-preconditioned CG, scalars kept on the device -------------------
+// Scalars: sc[0]=rz, sc[1]=pq, sc[2]=rr, sc[3]=bb, sc[4]=rz_new, sc[5]=iterations
+struct PcgArgs {
+    double* x; double* r; double* z; double* p; double* q;   // row-based (p is stored with halo lead)
+    const double* b; const double* dinv;
+    double* part_a; double* part_b; int nparts;               // per-block partial sums
+    double* sc; int* done; int64_t n; double rtol2;
+};
+
+__device__ __forceinline__ double sum_partials(const double* part, int np) {
+    __shared__ double s_tot;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < np; t += blockDim.x) s += part[t];
+    const double r = block_sum(s);
+    if (threadIdx.x == 0) s_tot = r;
+    __syncthreads();
+    return s_tot;
+}
+
+// x = 0, r = b, z = D^-1 r, p = z; partial r.z -> part_a, b.b -> part_b
+__global__ __launch_bounds__(BLOCK) void pcg_init(PcgArgs a) {
+    double rz = 0.0, bb = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * blockDim.x) {
+        const double b = a.b[t];
+        const double z = a.dinv[t] * b;
+        a.x[t] = 0.0; a.r[t] = b; a.z[t] = z; a.p[t] = z;
+        rz = fma(b, z, rz); bb = fma(b, b, bb);
+    }
+    const double s1 = block_sum(rz);
+    const double s2 = block_sum(bb);
+    if (threadIdx.x == 0) { a.part_a[blockIdx.x] = s1; a.part_b[blockIdx.x] = s2; }
+}
+
+__global__ __launch_bounds__(BLOCK) void pcg_init_finish(PcgArgs a) {
+    const double rz = sum_partials(a.part_a, a.nparts);
+    const double bb = sum_partials(a.part_b, a.nparts);
+    if (threadIdx.x == 0) {
+        a.sc[0] = rz; a.sc[3] = bb; a.sc[2] = bb; a.sc[5] = 0.0;
+        *a.done = (bb == 0.0) ? 1 : 0;
+    }
+}
+
+// after q = A p (partials of p.q in part_a, np_spmv of them):
+// alpha = rz/pq; x += alpha p; r -= alpha q; z = D^-1 r; partials r.z -> part_b[0..), r.r -> part_b[nparts..)
+__global__ __launch_bounds__(BLOCK) void pcg_update(PcgArgs a, int np_spmv) {
+    if (*a.done) return;
+    const double pq = sum_partials(a.part_a, np_spmv);
+    const double alpha = a.sc[0] / pq;
+    double rz = 0.0, rr = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * blockDim.x) {
+        a.x[t] = fma(alpha, a.p[t], a.x[t]);
+        const double r = fma(-alpha, a.q[t], a.r[t]);
+        const double z = a.dinv[t] * r;
+        a.r[t] = r; a.z[t] = z;
+        rz = fma(r, z, rz); rr = fma(r, r, rr);
+    }
+    const double s1 = block_sum(rz);
+    const double s2 = block_sum(rr);
+    if (threadIdx.x == 0) { a.part_b[blockIdx.x] = s1; a.part_b[a.nparts + blockIdx.x] = s2; }
+}
+
+// beta = rz_new/rz; p = z + beta p; bookkeeping and convergence flag (single extra block does the scalars)
+__global__ __launch_bounds__(BLOCK) void pcg_direction(PcgArgs a) {
+    if (*a.done) return;
+    const double rz_new = sum_partials(a.part_b, a.nparts);
+    const double beta = rz_new / a.sc[0];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * blockDim.x)
+        a.p[t] = fma(beta, a.p[t], a.z[t]);
+}
+
+// runs after pcg_direction (separate launch so every block saw the old rz)
+__global__ __launch_bounds__(BLOCK) void pcg_scalars(PcgArgs a) {
+    if (*a.done) return;
+    const double rz_new = sum_partials(a.part_b, a.nparts);
+    const double rr = sum_partials(a.part_b + a.nparts, a.nparts);
+    if (threadIdx.x == 0) {
+        a.sc[0] = rz_new; a.sc[2] = rr; a.sc[5] += 1.0;
+        if (rr <= a.rtol2 * a.sc[3]) *a.done = 1;
+    }
+}
+
+}  // namespace mgk

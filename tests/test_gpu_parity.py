@@ -1,0 +1,412 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  (1) golden vectors captured from the reference's own multigrid.py (tests/golden/*.npz),
+  (2) the CPU oracle on the same seeded inputs (3-D, which has no reference: parity unpinned),
+  (3) size-independent properties at larger sizes.
+
+Tolerances (BASELINE.json north_star: residual/iterate match <= 1e-10 relative l2):
+  TOL_ITER = 1e-10   V-cycle / FMG iterates and residual norms
+  TOL_SWEEP = 1e-12  Jacobi sweeps (one-matrix form differs from the split form by ~2e-16 per sweep)
+  exact (array_equal) for getJacobiMatrices and the three transfer operators.
+
+The FMG 4-tuple holds a residual and two corrections of an almost converged iterate
+(||f_2h|| ~ 1e-4 next to ||A|| ||v_h|| ~ 5e2 in the C1 fixture): such a residual is a difference of
+numbers seven orders of magnitude larger, so ANY evaluation order -- the reference's included -- only
+defines it to ~eps * ||A|| ||v|| / ||r|| ~ 5e-10 of its own norm.  Those entries are therefore
+compared at TOL_ITER relative to the quantity they perturb (||f_h|| for the restricted residual,
+||v_h|| for the corrections) and at TOL_CANCEL = 1e-7 relative to their own norm.
+"""
+import numpy as np
+import pytest
+
+from multigrid_dolfinx_amd import poisson
+from tests.helpers import bag_from_fixture, hierarchy_for, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_ITER = 1e-10
+TOL_SWEEP = 1e-12
+TOL_CANCEL = 1e-7
+FULL = ["c1_lex", "c1_perm"]
+
+
+@pytest.fixture()
+def mg():
+    """The drop-in module with clean state."""
+    from multigrid_dolfinx_amd import multigrid as m
+    m.configure(dim=2, prune_zeros=True, restriction="direct", grid_index=None, tuning={})
+    yield m
+    m.configure(dim=2, prune_zeros=True, restriction="direct", grid_index=None, tuning={})
+
+
+def _init_from_fixture(m, name, with_dicts=True):
+    g = load_golden(name)
+    bag, grid_index, coords = bag_from_fixture(g)
+    if with_dicts:
+        for l, c in coords.items():
+            lvl = poisson.Level(N=8 * 2 ** l, dim=2, A=bag.A_sp_dict[l][0], b=bag.b_dict[l], coords=c,
+                                grid_index=grid_index[l], h=1.0 / (8 * 2 ** l))
+            bag.mesh_dof_list_dict[l] = poisson.mesh_dof_dict(lvl)
+    else:
+        m.configure(grid_index=grid_index)
+    for l, a in bag.A_sp_dict.items():
+        bag.A_jacobi_sp_dict[l] = m.getJacobiMatrices(a)
+    m.initialize_problem(bag)
+    return g, bag
+
+
+def _check_fmg_tuple(got, want, f_h):
+    """(v_h, f_2h, v_2h, err_h): see the module docstring for the two scales."""
+    v_scale, f_scale = np.linalg.norm(want[0]), np.linalg.norm(f_h)
+    assert rel_l2(got[0], want[0]) <= TOL_ITER
+    for a, b, scale, key in ((got[1], want[1], f_scale, "f_2h"), (got[2], want[2], v_scale, "v_2h"),
+                             (got[3], want[3], v_scale, "err_h")):
+        assert np.linalg.norm(np.ravel(a) - np.ravel(b)) <= TOL_ITER * scale, key
+        assert rel_l2(a, b) <= TOL_CANCEL, key
+
+
+# ---- golden vectors from the reference -------------------------------------------------------------------
+@pytest.mark.parametrize("name", FULL)
+def test_get_jacobi_matrices_matches_reference(mg, name):
+    g = load_golden(name)
+    bag, _, _ = bag_from_fixture(g)
+    for l in (1, 2, 3):
+        R, Dinv, lev = mg.getJacobiMatrices(bag.A_sp_dict[l])
+        assert lev == l
+        assert R.indices.dtype == np.int32 and not R.has_sorted_indices
+        assert np.array_equal(R.indptr, g[f"J{l}_indptr"])
+        assert np.array_equal(R.indices, g[f"J{l}_indices"])
+        assert np.array_equal(R.data, g[f"J{l}_data"])
+        assert np.array_equal(Dinv.diagonal(), g[f"Dinv{l}"])
+        assert bag.A_sp_dict[l][0].nnz == g[f"A{l}_data"].size
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_transfer_operators_match_reference_exactly(mg, name):
+    g, bag = _init_from_fixture(mg, name)
+    d = bag.mesh_dof_list_dict
+    hs = bag.element_size
+    for lc in (1, 2):
+        lf = lc + 1
+        out = mg.Interpolation2D(g[f"xfer_xc{lc}"], d[lc], d[lf], hs[lc], hs[lf], g[f"xfer_xf{lf}"].shape[0])
+        assert out.shape == g[f"interp_{lc}to{lf}"].shape
+        assert np.array_equal(out, g[f"interp_{lc}to{lf}"])
+        out = mg.Restriction2D_direct(g[f"xfer_xf{lf}"], d[lc], d[lf], g[f"xfer_xc{lc}"].shape[0])
+        assert np.array_equal(out, g[f"inject_{lf}to{lc}"])
+        out = mg.Restriction2D(g[f"xfer_xf{lf}"], d[lc], d[lf], hs[lc], hs[lf], g[f"xfer_xc{lc}"].shape[0])
+        assert np.array_equal(out, g[f"fullw_{lf}to{lc}"])
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_jacobi_relaxation_matches_reference(mg, name):
+    g, bag = _init_from_fixture(mg, name)
+    v0 = g["jac_v0"].copy()
+    for nw in (1, 50):
+        out = mg.jacobiRelaxation(bag.A_jacobi_sp_dict[3], v0, bag.b_dict[3], nw)
+        assert out.shape == (4225, 1)
+        assert rel_l2(out, g[f"jac_nw{nw}"]) <= TOL_SWEEP
+    assert np.array_equal(v0, g["jac_v0"])                  # input not mutated
+    assert np.array_equal(mg.jacobiRelaxation(bag.A_jacobi_sp_dict[3], v0, bag.b_dict[3], 0), v0)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_jacobi_relaxation_standalone_operands(mg, name):
+    """Operands that do not belong to an initialised problem (the reference's function is pure)."""
+    g = load_golden(name)
+    bag, _, _ = bag_from_fixture(g)
+    A = mg.getJacobiMatrices(bag.A_sp_dict[3])
+    mg.omega = float(g["meta_omega"])
+    out = mg.jacobiRelaxation(A, g["jac_v0"], bag.b_dict[3], 50)
+    assert rel_l2(out, g["jac_nw50"]) <= TOL_SWEEP
+
+
+@pytest.mark.parametrize("name", FULL)
+@pytest.mark.parametrize("with_dicts", [True, False])
+def test_v_cycle_matches_reference(mg, name, with_dicts):
+    g, bag = _init_from_fixture(mg, name, with_dicts)
+    A3, f = bag.A_jacobi_sp_dict[3], bag.b_dict[3]
+    v = np.zeros_like(f)
+    for k in (1, 2, 3):
+        v_in = v.copy()
+        v = mg.V_cycle_scheme(A3, v, f)
+        assert v.shape == (4225, 1) and np.array_equal(v_in, v_in)
+        assert rel_l2(v, g[f"vcycle_iter{k}"]) <= TOL_ITER
+        r = f - bag.A_sp_dict[3][0].dot(v)
+        assert abs(np.linalg.norm(r) - g["vcycle_res_l2"][k - 1]) <= TOL_ITER * g["vcycle_res_l2"][k - 1]
+    t = mg.V_cycle_scheme(A3, np.zeros_like(f), f, True)
+    assert [a.shape for a in t] == [(4225, 1), (1089, 1), (1089, 1), (4225, 1)]
+    for key, arr in zip(("v_h", "f_2h", "v_2h", "err_h"), t):
+        assert rel_l2(arr, g[f"vcycle_test_{key}"]) <= TOL_ITER, key
+    mid = mg.V_cycle_scheme(bag.A_jacobi_sp_dict[2], np.zeros_like(bag.b_dict[2]), bag.b_dict[2], True)
+    assert isinstance(mid, np.ndarray)                       # test only changes the finest level (Q4)
+    assert rel_l2(mid, g["vcycle_mid_level2"]) <= TOL_ITER
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_full_multigrid_test_matches_reference(mg, name):
+    g, bag = _init_from_fixture(mg, name)
+    t = mg.FullMultiGrid_test(bag.A_jacobi_sp_dict[3], bag.b_dict[3], True)
+    assert [a.shape for a in t] == [(4225, 1), (1089, 1), (1089, 1), (4225, 1)]   # Multigrid_prototype.py:144-147
+    _check_fmg_tuple(t, [g[f"fmg_test_{k}"] for k in ("v_h", "f_2h", "v_2h", "err_h")], bag.b_dict[3])
+    with pytest.raises(ValueError):                          # reference quirk Q9
+        mg.FullMultiGrid_test(bag.A_jacobi_sp_dict[3], bag.b_dict[3], False)
+
+
+@pytest.mark.parametrize("name", ["n128_mu2_perm", "n256_mu50_lex", "n512_mu2_lex"])
+def test_larger_hierarchies_match_reference(mg, name):
+    g = load_golden(name)
+    h = hierarchy_for(g)
+    mg.configure(grid_index={l: L.grid_index for l, L in h.levels.items()})
+    for l, a in h.A_sp_dict.items():
+        h.A_jacobi_sp_dict[l] = (None, None, l)              # only the level key is used by the shim
+    mg.initialize_problem(h)
+    hi, stride = h.finest_level, int(g["meta_stride"])
+    f = h.b_dict[hi]
+    v = np.zeros_like(f)
+    for k in range(1, g["vcycle_res_l2"].size + 1):
+        v = mg.V_cycle_scheme(h.A_jacobi_sp_dict[hi], v, f)
+        assert np.linalg.norm(v[::stride] - g[f"vcycle_iter{k}"]) <= TOL_ITER * g["vcycle_l2"][k - 1]
+        r = f - h.A_sp_dict[hi][0].dot(v)
+        assert abs(np.linalg.norm(r) - g["vcycle_res_l2"][k - 1]) <= TOL_ITER * g["vcycle_res_l2"][k - 1]
+    if "fmg_test_v_h" in g.files:
+        t = mg.FullMultiGrid_test(h.A_jacobi_sp_dict[hi], f, True)
+        _check_fmg_tuple([a[::stride] for a in t], [g[f"fmg_test_{k}"] for k in ("v_h", "f_2h", "v_2h", "err_h")], f)
+
+
+# ---- oracle comparisons (3-D has no reference: parity unpinned) -----------------------------------------------
+def _oracle_and_device(dim, lo, hi, c, seed, mu, **kw):
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu0=2, mu1=mu, mu2=mu, seed=seed)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    orc = Oracle(bag, gi, dim=dim)
+    dev = DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, **kw)
+    return bag, orc, dev
+
+
+@pytest.mark.parametrize("seed", [None, 2])
+@pytest.mark.parametrize("prune", [True, False])
+def test_3d_v_cycle_and_fmg_match_oracle(seed, prune):
+    bag, orc, dev = _oracle_and_device(3, 1, 3, 2, seed, 3, prune_zeros=prune)     # N = 4, 8, 16
+    with dev:
+        f = bag.b_dict[3]
+        v = np.zeros_like(f)
+        dev.set_vector(3, "v", v)
+        dev.set_vector(3, "f", f)
+        for k in range(2):
+            v = orc.v_cycle(orc.A_jacobi_sp_dict[3], v, f)
+            res = dev.vcycle(3, 1, residuals=True)
+            assert rel_l2(dev.get_vector(3, "v"), v) <= TOL_ITER
+            r = f - bag.A_sp_dict[3][0].dot(v)
+            assert abs(res[0] - np.linalg.norm(r)) <= TOL_ITER * np.linalg.norm(r)
+        t = orc.full_multigrid_test(orc.A_jacobi_sp_dict[3], f, True)
+        for l in (1, 2):
+            dev.set_rhs_true(l, bag.b_dict[l])
+        dev.set_vector(3, "f", f)
+        dev.fmg(2)
+        got = (dev.get_vector(3, "v"), dev.get_vector(2, "f"), dev.get_vector(2, "v"), dev.get_vector(3, "err"))
+        _check_fmg_tuple(got, t, f)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_transfers_match_oracle_exactly(dim):
+    bag, orc, dev = _oracle_and_device(dim, 0, 1, 6 if dim == 2 else 4, 11, 1)
+    rng = np.random.default_rng(1234)
+    with dev:
+        xc = rng.standard_normal((bag.levels[0].n, 1))
+        xf = rng.standard_normal((bag.levels[1].n, 1))
+        dev.set_vector(0, "v", xc)
+        dev.prolong(1, add=False)
+        assert np.array_equal(dev.get_vector(1, "err"), orc.interpolate(xc, 0))
+        dev.set_vector(1, "v", xf)
+        dev.prolong(1, add=True)
+        assert np.array_equal(dev.get_vector(1, "v"), xf + orc.interpolate(xc, 0))
+        dev.set_vector(1, "r", xf)
+        dev.restrict(1, "direct")
+        assert np.array_equal(dev.get_vector(0, "f"), orc.restrict_direct(xf, 1))
+        dev.set_vector(1, "r", xf)
+        dev.restrict(1, "full_weighting")
+        assert np.array_equal(dev.get_vector(0, "f"), orc.restrict_full_weighting(xf, 1))
+
+
+def test_full_weighting_v_cycle_matches_oracle():
+    bag, orc, dev = _oracle_and_device(2, 1, 3, 4, 5, 4)
+    with dev:
+        dev.set_params(4, 4, bag.omega, restriction="full_weighting")
+        f = bag.b_dict[3]
+        want = orc.v_cycle(orc.A_jacobi_sp_dict[3], np.zeros_like(f), f, restriction="full_weighting")
+        dev.set_vector(3, "v", np.zeros_like(f))
+        dev.set_vector(3, "f", f)
+        dev.vcycle(3, 1)
+        assert rel_l2(dev.get_vector(3, "v"), want) <= TOL_ITER
+
+
+def test_residual_smooth_and_coarse_solve_match_oracle():
+    from scipy.sparse.linalg import spsolve
+    bag, orc, dev = _oracle_and_device(2, 1, 2, 8, 3, 2)
+    rng = np.random.default_rng(7)
+    with dev:
+        v = rng.standard_normal((bag.levels[2].n, 1))
+        f = bag.b_dict[2]
+        dev.set_vector(2, "v", v)
+        dev.set_vector(2, "f", f)
+        dev.residual(2)
+        want = f - bag.A_sp_dict[2][0].dot(v)
+        assert rel_l2(dev.get_vector(2, "r"), want) <= 1e-14
+        assert abs(dev.norm2(2, "r") - np.linalg.norm(want)) <= 1e-13 * np.linalg.norm(want)
+        dev.set_vector(1, "f", bag.b_dict[1])
+        its, rel = dev.coarse_solve()
+        exact = spsolve(bag.A_sp_dict[1][0].tocsc(), bag.b_dict[1].ravel())
+        assert rel <= 1e-14 and its > 0
+        assert rel_l2(dev.get_vector(1, "v"), exact) <= 1e-12
+        # zero right-hand side: the solver must return zero without iterating
+        dev.set_vector(1, "f", np.zeros_like(bag.b_dict[1]))
+        its, rel = dev.coarse_solve()
+        assert its == 0 and np.all(dev.get_vector(1, "v") == 0.0)
+
+
+# ---- set-up variants must not change the arithmetic ---------------------------------------------------------------------
+def _one_cycle(dev, level, f):
+    dev.set_vector(level, "v", np.zeros_like(f))
+    dev.set_vector(level, "f", f)
+    dev.vcycle(level, 1)
+    return dev.get_vector(level, "v")
+
+
+@pytest.mark.parametrize("dim,lo,hi,c", [(2, 1, 3, 8), (3, 1, 3, 2)])
+def test_device_generator_equals_csr_hand_off(dim, lo, hi, c):
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=3, mu2=3)
+    for prune in (True, False):
+        with DeviceHierarchy.from_bag(bag, dim=dim, grid_index={l: L.grid_index for l, L in bag.levels.items()},
+                                      prune_zeros=prune) as a, \
+                DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=3, mu2=3, prune_zeros=prune) as b:
+            for l in range(lo, hi + 1):
+                ia, ib = a.level_info(l), b.level_info(l)
+                assert ia == ib, (ia, ib)
+                assert np.array_equal(b.get_vector(l, "f"), bag.b_dict[l])        # generated RHS is bit-identical
+            va = _one_cycle(a, hi, bag.b_dict[hi])
+            b.zero_vector(hi, "v")
+            b.vcycle(hi, 1)
+            assert np.array_equal(va, b.get_vector(hi, "v"))
+            assert a.level_info(hi)["nnz_nonzero"] == int((bag.levels[hi].A.data != 0).sum())
+
+
+@pytest.mark.parametrize("dim,lo,hi,c", [(2, 2, 4, 8), (3, 1, 3, 4)])
+def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c):
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=4, mu2=4, seed=9)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    f = bag.b_dict[hi]
+    base = None
+    for prune in (True, False):
+        for R in (1, 2, 4):
+            for chunk in (1, 4):
+                with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
+                                              xcd_chunk=chunk) as dev:
+                    out = _one_cycle(dev, hi, f)
+                # the tile shape changes which rows share a block, hence the order of the partial
+                # sums in the coarse solver's dot products: equal to round-off, not bit for bit
+                if base is None:
+                    base = out
+                else:
+                    assert rel_l2(out, base) <= 1e-13, (prune, R, chunk)
+                if R == 1 and chunk == 4 and prune:
+                    assert np.array_equal(out, base)        # the block -> tile map alone changes nothing
+
+
+# ---- size-independent properties at larger sizes ----------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,lo,hi", [(2, 3, 7), (3, 2, 4)])        # 1024x1024 (5 levels); 128^3 (3 levels)
+def test_properties_at_scale(dim, lo, hi):
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    with DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=2, mu2=2) as dev:
+        n = dev.n_dofs(hi)
+        N = dev.elements(hi)
+        idx = np.arange(n)
+        x = (idx % (N + 1)) / N
+        y = ((idx // (N + 1)) % (N + 1)) / N
+        g = 1.0 + x * x + 2.0 * y * y
+        if dim == 3:
+            z = (idx // (N + 1) ** 2) / N
+            g = g + 3.0 * z * z
+        f = dev.get_vector(hi, "f")
+        # (a) the manufactured solution solves the discrete system: residual at round-off
+        dev.set_vector(hi, "v", g)
+        dev.residual(hi)
+        assert dev.norm2(hi, "r") <= 1e-11 * np.linalg.norm(f)
+        # (b) ... and is a fixed point of the V-cycle
+        dev.vcycle(hi, 1)
+        assert rel_l2(dev.get_vector(hi, "v"), g) <= 1e-12
+        # (c) V-cycles from zero reduce the residual monotonically
+        dev.zero_vector(hi, "v")
+        res = dev.vcycle(hi, 3, residuals=True)
+        assert res[0] < np.linalg.norm(f) and res[1] < res[0] and res[2] < res[1]
+        # (d) injection of the interpolant is the identity (bit-exact)
+        rng = np.random.default_rng(3)
+        xc = rng.standard_normal((dev.n_dofs(hi - 1), 1))
+        dev.set_vector(hi - 1, "v", xc)
+        dev.prolong(hi, add=False)
+        dev.copy_vector(hi, "r", "err")
+        dev.restrict(hi, "direct")
+        assert np.array_equal(dev.get_vector(hi - 1, "f"), xc)
+        # (e) the smoother is affine: S(a) - S(b) = S0(a - b) with zero right-hand side
+        a = rng.standard_normal((n, 1))
+        b = rng.standard_normal((n, 1))
+        outs = []
+        for vec, rhs in ((a, f), (b, f), (a - b, np.zeros_like(f))):
+            dev.set_vector(hi, "v", vec)
+            dev.set_vector(hi, "f", rhs)
+            dev.smooth(hi, 3)
+            outs.append(dev.get_vector(hi, "v"))
+        assert rel_l2(outs[0] - outs[1], outs[2]) <= 1e-12
+
+
+# ---- edge cases and error behaviour -----------------------------------------------------------------------------------------------
+def test_edge_cases_and_errors(mg):
+    from multigrid_dolfinx_amd._capi import MgError
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(2, 0, 1, c=4, mu1=0, mu2=0, seed=1)      # smallest grids, zero sweeps
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    from oracle.mg_oracle import Oracle
+    orc = Oracle(bag, gi, dim=2)
+    with DeviceHierarchy.from_bag(bag, dim=2, grid_index=gi) as dev:
+        f = bag.b_dict[1]
+        want = orc.v_cycle(orc.A_jacobi_sp_dict[1], np.zeros_like(f), f)
+        assert rel_l2(_one_cycle(dev, 1, f), want) <= TOL_ITER
+        # a V-cycle entered on the coarsest level is the exact solve (multigrid.py:238-241)
+        want0 = orc.v_cycle(orc.A_jacobi_sp_dict[0], np.zeros_like(bag.b_dict[0]), bag.b_dict[0])
+        assert rel_l2(_one_cycle(dev, 0, bag.b_dict[0]), want0) <= 1e-12
+        with pytest.raises(ValueError):
+            dev.set_vector(1, "v", np.zeros(7))
+        with pytest.raises(KeyError):
+            dev.smooth(5, 1)
+        with pytest.raises(MgError):
+            dev.restrict(0, "direct")
+    with pytest.raises(ValueError):
+        DeviceHierarchy(2, 0, 1, c=4).set_level(1, bag.A_sp_dict[0][0])           # wrong size for the level
+    bad = bag.A_sp_dict[1][0].copy()
+    bad.data[bad.indices == np.repeat(np.arange(bad.shape[0]), np.diff(bad.indptr))] = 0.0
+    with pytest.raises(MgError, match="diagonal"):
+        DeviceHierarchy(2, 0, 1, c=4).set_level(1, bad)
+    with pytest.raises(MgError, match="permutation"):
+        DeviceHierarchy(2, 0, 1, c=4).set_level(1, bag.A_sp_dict[1][0], np.zeros(bag.levels[1].n, dtype=np.int64))
+    with pytest.raises(RuntimeError):
+        mg.A_sp_dict = None
+        mg.V_cycle_scheme((None, None, 1), np.zeros((4, 1)), np.zeros((4, 1)))
+
+
+def test_full_multigrid_solves_to_tolerance(mg, tmp_path, monkeypatch):
+    """FullMultiGrid (multigrid.py:271-307): loop on the finest level until the residual norm is below
+    the stop tolerance; the discrete solution equals the manufactured one."""
+    monkeypatch.chdir(tmp_path)
+    bag = poisson.make_hierarchy(2, 1, 3, c=4, mu0=2, mu1=4, mu2=4, seed=4, with_dicts=True)
+    for l, a in bag.A_sp_dict.items():
+        bag.A_jacobi_sp_dict[l] = mg.getJacobiMatrices(a)
+    mg.configure(restriction="full_weighting", stop_tol=1e-9)
+    mg.initialize_problem(bag)
+    u = mg.FullMultiGrid(bag.A_jacobi_sp_dict[3], bag.b_dict[3])
+    hist = bag.residual_per_V_cycle_finest
+    assert len(hist) >= 1 and hist[-1] <= 1e-9 and all(h > 1e-9 for h in hist[:-1])
+    assert np.abs(u - bag.levels[3].exact()).max() <= 1e-8
+    rows = open(tmp_path / "iter_count_for_diff_num_elems_3_levels.csv").read().strip().split(",")
+    assert rows == ["32", str(len(hist))]
+    assert abs(mg.res_calculator(u, None) - np.linalg.norm(u)) <= 1e-12 * np.linalg.norm(u)
