@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycles/s and achieved HBM GB/s of the geometric-multigrid hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2|c1] [--mu 50]
+
+A "step" is one V(mu, mu) cycle (V_cycle_scheme, multigrid.py:231-268) of the synthetic P1
+Poisson hierarchy named by --config, device-resident from start to end (the hierarchy and the
+right-hand side are generated in HBM before the timed region).  Default = BASELINE.json's headline
+workload: 3-D, 6 levels, N = 1024 elements per dimension (1025^3 unknowns), V(50,50), omega = 2/3 --
+the reference's shipped smoother parameters (Multigrid_prototype.py:42-46).  With N > 1 GPUs the
+same grid is split into slabs (strong scaling); launch as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N ...
+torch is used for that rendezvous only (RCCL id broadcast, barrier, max over ranks; gloo); the data
+path is libmg_hip.so + RCCL.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (dim, coarsest_level, finest_level, description)            N_l = 8 * 2**l
+    "c1": (2, 1, 3, "2D Poisson P1, 3-level 64x64 fine grid"),
+    "c2": (2, 4, 8, "2D Poisson P1, 5-level 2048x2048 fine grid"),
+    "c3": (3, 2, 5, "3D Poisson P1, 4-level 256^3 fine grid"),
+    "c4": (3, 2, 7, "3D Poisson P1, 6-level 1024^3 fine grid"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--mu", type=int, default=50, help="pre- and post-smoothing sweeps (reference: 50)")
+    ap.add_argument("--omega", type=float, default=2.0 / 3.0)
+    ap.add_argument("--rows-per-lane", type=int, default=None)
+    ap.add_argument("--xcd-chunk", type=int, default=None)
+    ap.add_argument("--replicate-below", type=int, default=1 << 22,
+                    help="levels with fewer unknowns are replicated on every rank")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-level", type=int, default=4, help="finest level of the CPU sample (N = 8*2^l)")
+    return ap.parse_args()
+
+
+class Rendezvous:
+    """torch.distributed (gloo) for bootstrap, barrier and max-over-ranks only."""
+
+    def __init__(self, gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus:
+            if self.world == 1 and gpus > 1:
+                raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run "
+                                 "(one rank per GPU)")
+            raise SystemExit(f"--gpus {gpus} does not match WORLD_SIZE {self.world}")
+        self.dist = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def broadcast_bytes(self, payload):
+        if self.dist is None:
+            return payload
+        box = [payload]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def build_hierarchy(args, rv):
+    from multigrid_dolfinx_amd import _capi
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    import ctypes as C
+    dim, lo, hi, _ = CONFIGS[args.config]
+    tuning = {}
+    if args.rows_per_lane:
+        tuning["rows_per_lane"] = args.rows_per_lane
+    if args.xcd_chunk:
+        tuning["xcd_chunk"] = args.xcd_chunk
+
+    def comm(h):
+        if rv.world == 1:
+            return
+        uid = None
+        if rv.rank == 0:
+            buf = C.create_string_buffer(128)
+            _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
+            uid = buf.raw
+        uid = rv.broadcast_bytes(uid)
+        h.set_comm_rccl(rv.rank, rv.world, uid, replicate_below=args.replicate_below)
+
+    return DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega,
+                                     prune_zeros=True, device=rv.local_rank, comm=comm, **tuning)
+
+
+def timed_cycles(h, rv, level, warmup, steps):
+    h.zero_vector(level, "v")
+    if warmup:
+        h.vcycle(level, warmup)
+    h.sync()
+    rv.barrier()
+    t0 = time.perf_counter()
+    h.vcycle(level, steps)
+    h.sync()
+    rv.barrier()
+    return rv.max(time.perf_counter() - t0)
+
+
+def cpu_baseline(args):
+    """The oracle (a port of the reference's NumPy/SciPy V-cycle) on a bounded sample of the same
+    workload: same dimension, smoother and level count rule, smaller fine grid; 1 thread, like the
+    reference (SciPy csr_matvec / SuperLU do not thread)."""
+    from multigrid_dolfinx_amd import poisson
+    from oracle.mg_oracle import Oracle
+    dim, lo, hi, _ = CONFIGS[args.config]
+    s_hi = min(hi, args.cpu_sample_level if dim == 3 else 7)     # same coarsest grid, fewer fine levels
+    s_lo = min(lo, s_hi - 1)
+    bag = poisson.make_hierarchy(dim, s_lo, s_hi, c=8, mu0=1, mu1=args.mu, mu2=args.mu, omega=args.omega)
+    orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=dim)
+    f = bag.b_dict[s_hi]
+    v = np.zeros_like(f)
+    cycles, t0 = 0, time.perf_counter()
+    while cycles < 1 or (time.perf_counter() - t0 < 10.0 and cycles < 20):
+        v = orc.v_cycle(orc.A_jacobi_sp_dict[s_hi], v, f)
+        cycles += 1
+    dt = time.perf_counter() - t0
+    n_s = bag.levels[s_hi].n
+    n_full = (8 * 2 ** hi + 1) ** dim
+    per_s = cycles / dt
+    return {
+        "value": per_s * n_s / n_full, "unit": "V-cycles/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle/mg_oracle.py V({args.mu},{args.mu}) on a {s_hi - s_lo + 1}-level {dim}-D hierarchy with "
+                   f"N={8 * 2 ** s_hi} ({n_s} DoF): {cycles} cycles in {dt:.2f} s = {per_s:.4f} cycles/s on the "
+                   f"sample, scaled by DoF ({n_s}/{n_full}) to the benchmarked grid; host has {os.cpu_count()} "
+                   f"logical CPUs, 1 thread used"),
+        "sample_cycles_per_s": per_s, "sample_dofs": n_s,
+    }
+
+
+def main():
+    args = parse()
+    rv = Rendezvous(args.gpus)
+    dim, lo, hi, desc = CONFIGS[args.config]
+    t_setup = time.perf_counter()
+    h = build_hierarchy(args, rv)
+    h.sync()
+    t_setup = time.perf_counter() - t_setup
+
+    elapsed = timed_cycles(h, rv, hi, args.warmup, args.steps)
+    res_after = h.vcycle(hi, 1, residuals=True)[0]          # untimed: convergence evidence
+    f_norm = h.norm2(hi, "f")
+
+    # dominant kernel: one fine-level Jacobi sweep, HIP events on the handle's stream
+    info = h.level_info(hi)
+    jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
+    res_ms = h.time_kernel("residual", hi, args.kernel_reps)
+    n_loc, z_loc = info["n_local"], info["nnz_nonzero"]
+    bytes_jacobi = 12 * z_loc + 32 * n_loc                   # values+columns, read v f D^-1, write v (no row pointers)
+    bytes_resid = 12 * z_loc + 24 * n_loc
+    achieved = bytes_jacobi / (jac_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            key = f"{args.config}_gpus{args.gpus}"
+            traffic = t.get(key, {}).get("jacobi_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # conventional V(2,2) for information
+    h.set_params(2, 2, args.omega)
+    v22 = timed_cycles(h, rv, hi, 1, max(2, args.steps))
+    v22_per_s = max(2, args.steps) / v22
+    mem = h.memory_bytes()
+    dev = h.device_info()
+    h.close()
+
+    out = None
+    if rv.rank == 0:
+        per_s = args.steps / elapsed
+        out = {
+            "metric": "V-cycles/sec + achieved HBM GB/s, 3D Poisson P1 1024^3 DoF" if args.config == "c4"
+                      else f"V-cycles/sec + achieved HBM GB/s, {desc}",
+            "value": per_s, "unit": "V-cycles/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "
+                                   f"omega={args.omega:.4f}, injection, Q1 prolongation, PCG coarsest solve, "
+                                   f"explicit zeros pruned (7-point rows)" if dim == 3 else
+                                   f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi",
+                       "levels": hi - lo + 1, "dim": dim, "elements_per_dim": 8 * 2 ** hi,
+                       "parallelism": f"slab{args.gpus}" if args.gpus > 1 else "single"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ell_apply<W,R,JACOBI> (fine-level weighted-Jacobi sweep)",
+                         "kernel_ms": jac_ms, "algorithmic_bytes_per_launch": bytes_jacobi,
+                         "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
+                         "residual_kernel_ms": res_ms,
+                         "residual_achieved_GBs": bytes_resid / (res_ms * 1e-3) / 1e9},
+            "v22_cycles_per_s": v22_per_s, "residual_l2_after": res_after, "rhs_l2": f_norm,
+            "setup_s": t_setup, "device_memory_GB_per_gpu": mem / 1e9, "device": dev,
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+    rv.barrier()
+    rv.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
