@@ -141,8 +141,8 @@ struct mg_context {
     int coarse_maxit = 20000;
     int keep_err = 0;
     // tuning
-    int rows_per_lane = 1;
-    unsigned chunk = 1;
+    int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
+    unsigned chunk = 8;         // XCD chunk of the block -> tile map
     int pcg_chunk = 16;
     // scratch
     double* partials = nullptr;     // 2 * kMaxParts doubles
