@@ -1,0 +1,41 @@
+"""The N>1 path.  CPU (gloo, world_size 2): the slab scheme itself -- aligned plane splits, one halo plane
+per neighbour, replicated coarse levels -- restated in NumPy and checked against the serial oracle, plus
+bench.py's rendezvous.  GPU: two processes sharing one MI355X run the real HIP kernels on two slabs through
+the host-staged callback transport and must reproduce the single-handle result bit for bit."""
+import pytest
+
+from tests.dist_helpers import free_port, slab_splits
+
+
+def _spawn(fn, world, *args):
+    import torch.multiprocessing as mp
+    mp.spawn(fn, args=(world, free_port()) + args, nprocs=world, join=True)
+
+
+def test_slab_splits_are_aligned_between_levels():
+    for N0, world in ((32, 8), (16, 2), (8, 8), (12, 5)):
+        for l in range(0, 4):
+            s, sf = slab_splits(N0, l, world), slab_splits(N0, l + 1, world)
+            assert s[0] == 0 and s[-1] == N0 * 2 ** l + 1 and all(b > a for a, b in zip(s, s[1:]))
+            for r in range(world):
+                for K in range(s[r], s[r + 1]):
+                    assert sf[r] <= 2 * K < sf[r + 1]              # coarse plane K lives with fine plane 2K
+
+
+@pytest.mark.parametrize("dim,lo,hi,c,rep", [(2, 1, 3, 8, 1000), (3, 1, 3, 2, 200)])
+def test_slab_decomposition_reproduces_serial_cpu(dim, lo, hi, c, rep):
+    from tests.dist_workers import cpu_slab_worker
+    _spawn(cpu_slab_worker, 2, dim, lo, hi, c, 3, rep)
+
+
+def test_bench_rendezvous_over_gloo():
+    from tests.dist_workers import rendezvous_worker
+    _spawn(rendezvous_worker, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,lo,hi,c,rep,mode", [(2, 1, 3, 8, 1000, "csr"), (3, 1, 3, 2, 200, "gen"),
+                                                   (3, 1, 3, 4, 0, "gen")])
+def test_two_slabs_on_one_gpu_match_single_handle(dim, lo, hi, c, rep, mode):
+    from tests.dist_workers import gpu_slab_worker
+    _spawn(gpu_slab_worker, 2, dim, lo, hi, c, 2, rep, mode)
