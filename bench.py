@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--omega", type=float, default=2.0 / 3.0)
     ap.add_argument("--rows-per-lane", type=int, default=None)
     ap.add_argument("--xcd-chunk", type=int, default=None)
+    ap.add_argument("--offset-codes", type=int, default=None, help="0 = int32 column indices")
     ap.add_argument("--replicate-below", type=int, default=1 << 22,
                     help="levels with fewer unknowns are replicated on every rank")
     ap.add_argument("--kernel-reps", type=int, default=20)
@@ -109,6 +110,8 @@ def build_hierarchy(args, rv):
         tuning["rows_per_lane"] = args.rows_per_lane
     if args.xcd_chunk:
         tuning["xcd_chunk"] = args.xcd_chunk
+    if args.offset_codes is not None:
+        tuning["offset_codes"] = args.offset_codes
 
     def comm(h):
         if rv.world == 1:

@@ -74,6 +74,9 @@ int mg_device_info(mg_handle h, char* buf, size_t buflen);
 int mg_comm_unique_id(void* id_out, size_t id_bytes);
 int mg_set_comm(mg_handle h, int rank, int world, const void* nccl_unique_id, size_t id_bytes,
                 int64_t replicate_below);
+/* Exercises every RCCL entry point the library uses (id, init, all-reduce, broadcast, grouped
+ * send/recv, destroy) on a one-rank communicator of `device`; 0 = all results correct. */
+int mg_comm_selftest(int device);
 /* Host-staged transport for tests without RCCL peers: the library stages device
  * buffers through host memory and calls back into the caller (who moves the bytes,
  * e.g. over gloo).  exchange: send `count` doubles to rank-1 / rank+1 (NULL pointer
@@ -135,7 +138,8 @@ int mg_set_tuning(mg_handle h, const char* key, int64_t value);
 
 /* ---- level queries ------------------------------------------------------------------- */
 int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, int64_t* row0,
-                  int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated);
+                  int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated,
+                  int* offset_codes /* 0 = int32 columns, else number of distinct offsets */);
 
 /* ---- vectors ---------------------------------------------------------------------------
  * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the

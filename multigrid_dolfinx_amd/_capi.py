@@ -36,6 +36,7 @@ SIGNATURES = {
     "mg_device_info": [_H, C.c_char_p, C.c_size_t],
     "mg_comm_unique_id": [C.c_void_p, C.c_size_t],
     "mg_set_comm": [_H, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int64],
+    "mg_comm_selftest": [C.c_int],
     "mg_set_comm_callbacks": [_H, C.c_int, C.c_int, EXCHANGE_FN, ALLREDUCE_FN, ALLGATHERV_FN, C.c_void_p, C.c_int64],
     "mg_set_level_csr": [_H, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                          C.c_void_p, C.c_int],
@@ -45,7 +46,7 @@ SIGNATURES = {
                         C.c_void_p, C.c_void_p],
     "mg_set_params": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int],
     "mg_set_tuning": [_H, C.c_char_p, C.c_int64],
-    "mg_level_info": [_H, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _ip, _ip],
+    "mg_level_info": [_H, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _ip, _ip, _ip],
     "mg_set_vector": [_H, C.c_int, C.c_int, C.c_void_p],
     "mg_get_vector": [_H, C.c_int, C.c_int, C.c_void_p, C.c_int],
     "mg_zero_vector": [_H, C.c_int, C.c_int],

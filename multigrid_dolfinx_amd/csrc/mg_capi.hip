@@ -119,7 +119,11 @@ struct Level {
     int W = 0, R = 1;
     int64_t nslices = 0;
     double* vals = nullptr;
-    int* cols = nullptr;
+    int* cols = nullptr;                    // freed once the offset codes exist
+    unsigned long long* codes = nullptr;    // offset-coded columns (see mg_kernels.hip.h)
+    int* offsets = nullptr;
+    int ntable = 0, dcode = 0;
+    bool coded = false;
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
     int* perm = nullptr;
@@ -141,6 +145,7 @@ struct mg_context {
     int coarse_maxit = 20000;
     int keep_err = 0;
     // tuning
+    int use_codes = 1;          // offset-coded columns where a level allows it
     int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
     unsigned chunk = 8;         // XCD chunk of the block -> tile map
     int pcg_chunk = 16;
@@ -182,20 +187,24 @@ void dev_free(mg_context* c, T*& p, size_t count) {
     }
 }
 
+// Elements past the end of every vector: rows of the last, partly filled slice read (and ignore)
+// x[row] for up to 64*R - 1 rows beyond nloc in the offset-coded kernels.
+constexpr int64_t kVecSlack = 260;
+
 int vec_alloc(mg_context* c, const Level& L, DVector* v) {
     if (v->raw) return 0;
     const int64_t pad = (4 - (L.g.lead % 4)) % 4;
-    MG_TRY(dev_alloc(c, &v->raw, (size_t)(L.xlen + pad + 4)));
+    MG_TRY(dev_alloc(c, &v->raw, (size_t)(L.xlen + pad + kVecSlack)));
     v->base = v->raw + pad;
     v->rows = v->base + L.g.lead;
-    HIP_TRY(hipMemsetAsync(v->raw, 0, (size_t)(L.xlen + pad + 4) * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(v->raw, 0, (size_t)(L.xlen + pad + kVecSlack) * sizeof(double), c->stream));
     return 0;
 }
 
 void vec_free(mg_context* c, const Level& L, DVector* v) {
     if (v->raw) {
         const int64_t pad = (4 - (L.g.lead % 4)) % 4;
-        dev_free(c, v->raw, (size_t)(L.xlen + pad + 4));
+        dev_free(c, v->raw, (size_t)(L.xlen + pad + kVecSlack));
         v->base = v->rows = nullptr;
     }
 }
@@ -291,6 +300,9 @@ void free_level(mg_context* c, Level& L) {
     const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
     dev_free(c, L.vals, ell);
     dev_free(c, L.cols, ell);
+    dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * (WAVE * L.R));
+    dev_free(c, L.offsets, 256);
+    L.coded = false;
     dev_free(c, L.dinv, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.perm, (size_t)L.n_global);
     vec_free(c, L, &L.v);
@@ -315,6 +327,30 @@ void launch_ell_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStrea
         hipLaunchKernelGGL((ell_apply<WT, R, MODE_SPMV, false>), dim3(grid), dim3(BLOCK), 0, s, a);
 }
 
+template <int WT, int R>
+void launch_ell_coded_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (mode == MODE_RESIDUAL)
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_RESIDUAL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_JACOBI)
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_JACOBI, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (dot)
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
+// widths with an offset-coded specialisation
+inline bool coded_width(int W) { return W == 5 || W == 7 || W == 15; }
+
+template <int R>
+void launch_ell_coded_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+    switch (W) {
+        case 5: launch_ell_coded_wr<5, R>(mode, dot, a, grid, s); break;
+        case 7: launch_ell_coded_wr<7, R>(mode, dot, a, grid, s); break;
+        default: launch_ell_coded_wr<15, R>(mode, dot, a, grid, s); break;
+    }
+}
+
 template <int R>
 void launch_ell_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
     switch (W) {
@@ -332,8 +368,19 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
     a.slice0 = 0; a.nslices = L.nslices; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
+    a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
     const unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
     if (grid_out) *grid_out = grid;
+    if (L.coded) {
+        switch (L.R) {
+            case 1: launch_ell_coded_r<1>(L.W, mode, dot, a, grid, c->stream); break;
+            case 2: launch_ell_coded_r<2>(L.W, mode, dot, a, grid, c->stream); break;
+            case 4: launch_ell_coded_r<4>(L.W, mode, dot, a, grid, c->stream); break;
+            default: return fail("unsupported rows_per_lane");
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     switch (L.R) {
         case 1: launch_ell_r<1>(L.W, mode, dot, a, grid, c->stream); break;
         case 2: launch_ell_r<2>(L.W, mode, dot, a, grid, c->stream); break;
@@ -630,6 +677,64 @@ int upload_vector(mg_context* c, Level& L, DVector& v, const double* host) {
     return 0;
 }
 
+// Replace the int32 column array by offset codes when the level has <= 255 distinct col - row
+// values and a specialised width; otherwise the int32 kernels stay in use.
+int encode_level(mg_context* c, Level& L) {
+    if (!c->use_codes || !coded_width(L.W)) return 0;
+    int* d_table = nullptr;
+    int* d_count = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_table), kDeltaSlots * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_count), 2 * sizeof(int)));
+    std::vector<int> h_table(kDeltaSlots, kDeltaEmpty);
+    int h_counts[2] = {0, 0};
+    int rc = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d_table, h_table.data(), kDeltaSlots * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(d_count, 0, 2 * sizeof(int), c->stream));
+        const int64_t total = L.nslices * L.W * (WAVE * L.R);
+        const dim3 grid(blocks_for(total, 256)), blk(256);
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(ell_collect_deltas<1>, grid, blk, 0, c->stream, L.cols, L.nslices, L.W, L.nloc, L.g.lead, d_table, d_count); break;
+            case 2: hipLaunchKernelGGL(ell_collect_deltas<2>, grid, blk, 0, c->stream, L.cols, L.nslices, L.W, L.nloc, L.g.lead, d_table, d_count); break;
+            default: hipLaunchKernelGGL(ell_collect_deltas<4>, grid, blk, 0, c->stream, L.cols, L.nslices, L.W, L.nloc, L.g.lead, d_table, d_count); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_counts, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_table.data(), d_table, kDeltaSlots * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    (void)hipFree(d_table);
+    (void)hipFree(d_count);
+    if (rc) return rc;
+    const int h_count = h_counts[0];
+    if (h_counts[1] || h_count > 255) return 0;     // irregular numbering: keep int32 columns
+    std::vector<int> offs;
+    for (int v : h_table)
+        if (v != kDeltaEmpty) offs.push_back(v);
+    std::sort(offs.begin(), offs.end());
+    if ((int)offs.size() != h_count) return fail("offset table is inconsistent");
+    const auto zero = std::find(offs.begin(), offs.end(), 0);
+    if (zero == offs.end()) return fail("offset table lacks the diagonal");
+    L.ntable = (int)offs.size();
+    L.dcode = (int)(zero - offs.begin());
+    offs.resize(256, 0);
+    MG_TRY(dev_alloc(c, &L.offsets, 256));
+    HIP_TRY(hipMemcpyAsync(L.offsets, offs.data(), 256 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int CW = (L.W + 7) / 8;
+    MG_TRY(dev_alloc(c, &L.codes, (size_t)L.nslices * CW * (WAVE * L.R)));
+    const dim3 grid(blocks_for(L.nslices * (WAVE * L.R), 256)), blk(256);
+    switch (L.R) {
+        case 1: hipLaunchKernelGGL(ell_encode<1>, grid, blk, 0, c->stream, L.cols, L.codes, L.nslices, L.W, L.nloc, L.g.lead, L.offsets, L.ntable, L.dcode); break;
+        case 2: hipLaunchKernelGGL(ell_encode<2>, grid, blk, 0, c->stream, L.cols, L.codes, L.nslices, L.W, L.nloc, L.g.lead, L.offsets, L.ntable, L.dcode); break;
+        default: hipLaunchKernelGGL(ell_encode<4>, grid, blk, 0, c->stream, L.cols, L.codes, L.nslices, L.W, L.nloc, L.g.lead, L.offsets, L.ntable, L.dcode); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, L.cols, (size_t)L.nslices * L.W * (WAVE * L.R));      // 4*W bytes per row back
+    L.coded = true;
+    return 0;
+}
+
 int finish_level(mg_context* c, Level& L) {
     MG_TRY(alloc_level_vectors(c, L));
     L.set = true;
@@ -753,6 +858,42 @@ int mg_comm_unique_id(void* id_out, size_t id_bytes) {
     return 0;
 }
 
+int mg_comm_selftest(int device) {
+    MG_TRY(load_rccl());
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&comm, 1, id, 0));
+    hipStream_t s = nullptr;
+    double* d = nullptr;
+    const int n = 1024;
+    std::vector<double> h(3 * n);
+    for (int i = 0; i < n; ++i) { h[i] = 1.0 + i; h[n + i] = 0.0; h[2 * n + i] = -1.0; }
+    int rc = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 3 * n * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(d, h.data(), 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+        NCCL_TRY(g_rccl.AllReduce(d, d, n, ncclDouble, ncclSum, comm, s));            // one rank: unchanged
+        NCCL_TRY(g_rccl.GroupStart());
+        NCCL_TRY(g_rccl.Broadcast(d, d, n, ncclDouble, 0, comm, s));
+        NCCL_TRY(g_rccl.GroupEnd());
+        NCCL_TRY(g_rccl.GroupStart());
+        NCCL_TRY(g_rccl.Send(d, n, ncclDouble, 0, comm, s));                          // to self
+        NCCL_TRY(g_rccl.Recv(d + n, n, ncclDouble, 0, comm, s));
+        NCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipMemcpyAsync(h.data(), d, 3 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i)
+            if (h[i] != 1.0 + i || h[n + i] != 1.0 + i || h[2 * n + i] != -1.0) return fail("RCCL self-test: wrong data");
+        return 0;
+    }();
+    if (d) (void)hipFree(d);
+    if (s) (void)hipStreamDestroy(s);
+    g_rccl.CommDestroy(comm);
+    return rc;
+}
+
 static int comm_common(mg_handle c, int rank, int world, int64_t replicate_below) {
     if (!c) return fail("null handle");
     if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
@@ -811,6 +952,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "xcd_chunk") {
         if (value < 1 || value > 4096) return fail("xcd_chunk out of range");
         c->chunk = (unsigned)value;
+    } else if (k == "offset_codes") {
+        for (auto& L : c->L)
+            if (L.set) return fail("offset_codes must be chosen before level set-up");
+        c->use_codes = value != 0;
     } else if (k == "pcg_chunk") {
         if (value < 1) return fail("pcg_chunk must be positive");
         c->pcg_chunk = (int)value;
@@ -890,6 +1035,7 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     cleanup();
+    MG_TRY(encode_level(c, L));
     L.has_matrix = true;
     return finish_level(c, L);
 }
@@ -950,6 +1096,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     L.nnz_stored = counts[0];
     L.nnz_nonzero = counts[1];
+    MG_TRY(encode_level(c, L));
     // the generated right-hand side is also this level's true right-hand side for mg_fmg
     if (level + 1 < c->nlev) {
         MG_TRY(vec_alloc(c, L, &L.ftrue));
@@ -1001,7 +1148,7 @@ int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr,
 }
 
 int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, int64_t* row0, int64_t* nnz_stored,
-                  int64_t* nnz_nonzero, int* ell_width, int* replicated) {
+                  int64_t* nnz_nonzero, int* ell_width, int* replicated, int* offset_codes) {
     MG_TRY(check_level(c, level));
     const Level& L = c->L[level];
     if (n_global) *n_global = L.n_global;
@@ -1011,6 +1158,7 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
     if (nnz_nonzero) *nnz_nonzero = (int64_t)L.nnz_nonzero;
     if (ell_width) *ell_width = L.W;
     if (replicated) *replicated = L.replicated ? 1 : 0;
+    if (offset_codes) *offset_codes = L.coded ? L.ntable : 0;
     return 0;
 }
 

@@ -76,7 +76,8 @@ class DeviceHierarchy:
     """One multigrid hierarchy resident on one MI355X (or one slab of it per rank)."""
 
     def __init__(self, dim: int, coarsest_level: int, finest_level: int, c: int = 8, device: int = 0,
-                 rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None):
+                 rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
+                 offset_codes: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -90,6 +91,8 @@ class DeviceHierarchy:
             self.set_tuning("rows_per_lane", rows_per_lane)
         if xcd_chunk is not None:
             self.set_tuning("xcd_chunk", xcd_chunk)
+        if offset_codes is not None:
+            self.set_tuning("offset_codes", offset_codes)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):
@@ -240,13 +243,14 @@ class DeviceHierarchy:
     # ---- queries -------------------------------------------------------------------------------
     def level_info(self, level: int) -> dict:
         vals = [C.c_int64() for _ in range(5)]
-        w, rep = C.c_int(), C.c_int()
+        w, rep, codes = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.mg_level_info(self._h, self._idx(level), *[C.byref(v) for v in vals], C.byref(w),
-                                      C.byref(rep)))
+                                      C.byref(rep), C.byref(codes)))
         keys = ("n_global", "n_local", "row0", "nnz_stored", "nnz_nonzero")
         out = {k: int(v.value) for k, v in zip(keys, vals)}
         out["ell_width"] = int(w.value)
         out["replicated"] = bool(rep.value)
+        out["offset_codes"] = int(codes.value)
         return out
 
     def memory_bytes(self) -> int:

@@ -39,3 +39,11 @@ def test_bench_rendezvous_over_gloo():
 def test_two_slabs_on_one_gpu_match_single_handle(dim, lo, hi, c, rep, mode):
     from tests.dist_workers import gpu_slab_worker
     _spawn(gpu_slab_worker, 2, dim, lo, hi, c, 2, rep, mode)
+
+
+@pytest.mark.gpu
+def test_rccl_entry_points_on_one_rank():
+    """Every RCCL call the slab transport makes (unique id by value, init, all-reduce, grouped
+    broadcast, grouped send/recv, destroy), on a one-rank communicator -- all a 1-GPU box can run."""
+    from multigrid_dolfinx_amd import _capi
+    _capi.check(_capi.load().mg_comm_selftest(0))

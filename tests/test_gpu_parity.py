@@ -304,6 +304,13 @@ def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c):
                 with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
                                               xcd_chunk=chunk) as dev:
                     out = _one_cycle(dev, hi, f)
+                    assert dev.level_info(hi)["offset_codes"] in (5, 7, 15)       # coded columns in use
+                if chunk == 1:
+                    # int32 column indices + streamed D^-1: same arithmetic, bit for bit
+                    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
+                                                  xcd_chunk=chunk, offset_codes=0) as dev:
+                        assert dev.level_info(hi)["offset_codes"] == 0
+                        assert np.array_equal(_one_cycle(dev, hi, f), out), (prune, R)
                 # the tile shape changes which rows share a block, hence the order of the partial
                 # sums in the coarse solver's dot products: equal to round-off, not bit for bit
                 if base is None:
