@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--rows-per-lane", type=int, default=None)
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--offset-codes", type=int, default=None, help="0 = int32 column indices")
+    ap.add_argument("--strip-slices", type=int, default=None, help="XCD strip traversal (0 = off)")
+    ap.add_argument("--nontemporal", type=int, default=None)
     ap.add_argument("--replicate-below", type=int, default=1 << 22,
                     help="levels with fewer unknowns are replicated on every rank")
     ap.add_argument("--kernel-reps", type=int, default=20)
@@ -112,6 +114,10 @@ def build_hierarchy(args, rv):
         tuning["xcd_chunk"] = args.xcd_chunk
     if args.offset_codes is not None:
         tuning["offset_codes"] = args.offset_codes
+    if args.strip_slices is not None:
+        tuning["strip_slices"] = args.strip_slices
+    if args.nontemporal is not None:
+        tuning["nontemporal"] = args.nontemporal
 
     def comm(h):
         if rv.world == 1:

@@ -146,6 +146,8 @@ struct mg_context {
     int keep_err = 0;
     // tuning
     int use_codes = 1;          // offset-coded columns where a level allows it
+    int strip_slices = 0;       // XCD strip traversal for 3-D levels (0 = chunked map only; measured: no gain)
+    int nontemporal = 1;        // streaming loads for matrix / rhs data
     int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
     unsigned chunk = 8;         // XCD chunk of the block -> tile map
     int pcg_chunk = 16;
@@ -327,27 +329,33 @@ void launch_ell_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStrea
         hipLaunchKernelGGL((ell_apply<WT, R, MODE_SPMV, false>), dim3(grid), dim3(BLOCK), 0, s, a);
 }
 
-template <int WT, int R>
-void launch_ell_coded_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+template <int WT, int R, bool NT>
+void launch_ell_coded_wrn(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
     if (mode == MODE_RESIDUAL)
-        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_RESIDUAL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_JACOBI)
-        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_JACOBI, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (dot)
-        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
+template <int WT, int R>
+void launch_ell_coded_wr(int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (nt) launch_ell_coded_wrn<WT, R, true>(mode, dot, a, grid, s);
+    else launch_ell_coded_wrn<WT, R, false>(mode, dot, a, grid, s);
 }
 
 // widths with an offset-coded specialisation
 inline bool coded_width(int W) { return W == 5 || W == 7 || W == 15; }
 
 template <int R>
-void launch_ell_coded_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+void launch_ell_coded_r(int W, int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s) {
     switch (W) {
-        case 5: launch_ell_coded_wr<5, R>(mode, dot, a, grid, s); break;
-        case 7: launch_ell_coded_wr<7, R>(mode, dot, a, grid, s); break;
-        default: launch_ell_coded_wr<15, R>(mode, dot, a, grid, s); break;
+        case 5: launch_ell_coded_wr<5, R>(mode, dot, nt, a, grid, s); break;
+        case 7: launch_ell_coded_wr<7, R>(mode, dot, nt, a, grid, s); break;
+        default: launch_ell_coded_wr<15, R>(mode, dot, nt, a, grid, s); break;
     }
 }
 
@@ -369,18 +377,31 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
     a.slice0 = 0; a.nslices = L.nslices; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
-    const unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
-    if (grid_out) *grid_out = grid;
+    unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
     if (L.coded) {
+        // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
+        const int64_t ps = ((L.g.plane / (WAVE * L.R)) / 4) * 4;
+        const int ss = (c->strip_slices / 4) * 4;
+        if (ss > 0 && !dot && L.g.nz > 1 && ps >= 16 * (int64_t)ss && L.nslices < ((int64_t)1 << 31)) {
+            a.strip_ss = (unsigned)ss;
+            a.ps = (unsigned)ps;
+            a.kp = (unsigned)((L.nslices + ps - 1) / ps);
+            const int64_t strips = (ps + ss - 1) / ss;
+            const int64_t g = 8 * ((strips + 7) / 8) * (int64_t)a.kp * (ss / 4);
+            if (g < ((int64_t)1 << 31)) grid = (unsigned)g; else a.strip_ss = 0;
+        }
+        if (grid_out) *grid_out = grid;
+        const bool nt = c->nontemporal != 0;
         switch (L.R) {
-            case 1: launch_ell_coded_r<1>(L.W, mode, dot, a, grid, c->stream); break;
-            case 2: launch_ell_coded_r<2>(L.W, mode, dot, a, grid, c->stream); break;
-            case 4: launch_ell_coded_r<4>(L.W, mode, dot, a, grid, c->stream); break;
+            case 1: launch_ell_coded_r<1>(L.W, mode, dot, nt, a, grid, c->stream); break;
+            case 2: launch_ell_coded_r<2>(L.W, mode, dot, nt, a, grid, c->stream); break;
+            case 4: launch_ell_coded_r<4>(L.W, mode, dot, nt, a, grid, c->stream); break;
             default: return fail("unsupported rows_per_lane");
         }
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (grid_out) *grid_out = grid;
     switch (L.R) {
         case 1: launch_ell_r<1>(L.W, mode, dot, a, grid, c->stream); break;
         case 2: launch_ell_r<2>(L.W, mode, dot, a, grid, c->stream); break;
@@ -956,6 +977,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         for (auto& L : c->L)
             if (L.set) return fail("offset_codes must be chosen before level set-up");
         c->use_codes = value != 0;
+    } else if (k == "strip_slices") {
+        if (value < 0 || value > 4096 || value % 4) return fail("strip_slices must be a multiple of 4 in 0..4096");
+        c->strip_slices = (int)value;
+    } else if (k == "nontemporal") {
+        c->nontemporal = value != 0;
     } else if (k == "pcg_chunk") {
         if (value < 1) return fail("pcg_chunk must be positive");
         c->pcg_chunk = (int)value;

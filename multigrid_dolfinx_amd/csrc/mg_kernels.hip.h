@@ -33,6 +33,7 @@ constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 
 template <int R> struct alignas(8 * R) DVec { double d[R]; };
 template <int R> struct alignas(4 * R) IVec { int d[R]; };
+template <int R> struct alignas(8 * R) UVec { unsigned long long d[R]; };
 
 enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
 
@@ -103,22 +104,81 @@ struct EllArgs {
     const int* offsets;
     int ntable;
     int dcode;              // code of offset 0 (the diagonal / padding)
+    // XCD strip traversal (0 = chunked map): see strip_block()
+    unsigned strip_ss;      // slices per strip (multiple of 4)
+    unsigned ps;            // slices per pseudo-plane (multiple of 4)
+    unsigned kp;            // pseudo-planes
 };
 
-template <int R> struct alignas(8 * R) UVec { unsigned long long d[R]; };
+// ---- XCD strip traversal ----------------------------------------------------------------------
+// For 3-D grids the k+-1 neighbours of a row are a whole plane (8.4 MB at 1025^2) away, far beyond a
+// 4 MiB XCD L2, so with a plane-by-plane sweep every x line is pulled across the fabric ~4 times.
+// Here each XCD instead walks a STRIP of ~8 grid lines through all planes: the slices are viewed as
+// pseudo-planes of `ps` slices (the plane size rounded to whole slices; the ~1-row drift per plane
+// only blurs locality), a strip is `strip_ss` consecutive slices of a pseudo-plane, strips are dealt
+// to the 8 XCDs (s % 8), and the blocks of one XCD (blockIdx % 8, dealt round-robin by the dispatcher)
+// enumerate (strip, plane, block-in-strip) with the plane index fastest.  The three x planes a strip
+// touches at step k (~64 KB each) are then still in that XCD's L2 at steps k+1 and k+2.  It is a
+// bijection on slices whatever the dispatcher does: placement changes speed only.
+// Returns the first slice of the block's 4-slice group, or -1 for a padding block.
+__device__ __forceinline__ int64_t strip_block(const EllArgs& a, unsigned b) {
+    const unsigned x = b & 7u, q = b >> 3;
+    const unsigned bpt = a.strip_ss >> 2;
+    const unsigned bi = q % bpt, t = q / bpt;
+    const unsigned k = t % a.kp, sx = t / a.kp;
+    const unsigned in_plane = (sx * 8u + x) * a.strip_ss + bi * 4u;
+    if (in_plane >= a.ps) return -1;
+    return (int64_t)k * a.ps + in_plane;
+}
+
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+typedef double dvec4_t __attribute__((ext_vector_type(4)));
+typedef unsigned long long uvec2_t __attribute__((ext_vector_type(2)));
+typedef unsigned long long uvec4_t __attribute__((ext_vector_type(4)));
+
+// Streaming (non-temporal) loads/stores for data touched once per sweep, so that they do not evict
+// the re-used x lines from L2.
+template <int R, bool NT> __device__ __forceinline__ DVec<R> load_d(const double* p) {
+    DVec<R> o;
+    if (!NT) return *reinterpret_cast<const DVec<R>*>(p);
+    if (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
+    else if (R == 2) { const dvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
+    else { const dvec4_t t = __builtin_nontemporal_load(reinterpret_cast<const dvec4_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; o.d[2 % R] = t.z; o.d[3 % R] = t.w; }
+    return o;
+}
+template <int R, bool NT> __device__ __forceinline__ UVec<R> load_u(const unsigned long long* p) {
+    UVec<R> o;
+    if (!NT) return *reinterpret_cast<const UVec<R>*>(p);
+    if (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
+    else if (R == 2) { const uvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const uvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
+    else { const uvec4_t t = __builtin_nontemporal_load(reinterpret_cast<const uvec4_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; o.d[2 % R] = t.z; o.d[3 % R] = t.w; }
+    return o;
+}
+template <int R, bool NT> __device__ __forceinline__ void store_d(double* p, const DVec<R>& v) {
+    if (!NT) { *reinterpret_cast<DVec<R>*>(p) = v; return; }
+    if (R == 1) { __builtin_nontemporal_store(v.d[0], p); }
+    else if (R == 2) { dvec2_t t; t.x = v.d[0]; t.y = v.d[1]; __builtin_nontemporal_store(t, reinterpret_cast<dvec2_t*>(p)); }
+    else { dvec4_t t; t.x = v.d[0]; t.y = v.d[1]; t.z = v.d[2 % R]; t.w = v.d[3 % R]; __builtin_nontemporal_store(t, reinterpret_cast<dvec4_t*>(p)); }
+}
 
 // Offset-coded variant of ell_apply (same modes, same arithmetic, 8 B of column data per row).
-template <int WT, int R, int MODE, bool DOT>
+template <int WT, int R, int MODE, bool DOT, bool NT>
 __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
     __shared__ int s_off[256];
     if (a.done_flag && *a.done_flag) return;
-    for (int t = threadIdx.x; t < a.ntable; t += BLOCK) s_off[t] = a.offsets[t];
-    __syncthreads();
     constexpr int CW = (WT + 7) / 8;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const unsigned b = swizzle_block(blockIdx.x, gridDim.x, a.chunk);
-    const int64_t sl = (int64_t)b * WAVES_PER_BLOCK + wave;
+    int64_t sl;
+    if (a.strip_ss) {
+        const int64_t first = strip_block(a, blockIdx.x);
+        if (!DOT && first < 0) return;
+        sl = first < 0 ? a.nslices : first + wave;
+    } else {
+        sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    }
+    for (int t = threadIdx.x; t < a.ntable; t += BLOCK) s_off[t] = a.offsets[t];
+    __syncthreads();
     double dot = 0.0;
     if (sl < a.nslices) {
         const int64_t slice = a.slice0 + sl;
@@ -129,11 +189,9 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
         DVec<R> v[WT];
         UVec<R> cw[CW];
 #pragma unroll
-        for (int q = 0; q < CW; ++q)
-            cw[q] = *reinterpret_cast<const UVec<R>*>(a.codes + cbase + (size_t)q * (WAVE * R));
+        for (int q = 0; q < CW; ++q) cw[q] = load_u<R, NT>(a.codes + cbase + (size_t)q * (WAVE * R));
 #pragma unroll
-        for (int k = 0; k < WT; ++k)
-            v[k] = *reinterpret_cast<const DVec<R>*>(a.vals + base + (size_t)k * (WAVE * R));
+        for (int k = 0; k < WT; ++k) v[k] = load_d<R, NT>(a.vals + base + (size_t)k * (WAVE * R));
         double acc[R], diag[R], xr[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { acc[r] = 0.0; diag[r] = 1.0; xr[r] = 0.0; }
@@ -162,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
                     for (int r = 0; r < R; ++r) dot += xr[r] * acc[r];
                 }
             } else {
-                const DVec<R> fr = *reinterpret_cast<const DVec<R>*>(a.f + row);
+                const DVec<R> fr = load_d<R, NT>(a.f + row);
                 if (MODE == MODE_RESIDUAL) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) o.d[r] = fr.d[r] - acc[r];
@@ -171,7 +229,8 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
                     for (int r = 0; r < R; ++r) o.d[r] = xr[r] + (a.omega * (1.0 / diag[r])) * (fr.d[r] - acc[r]);
                 }
             }
-            *reinterpret_cast<DVec<R>*>(a.out + row) = o;
+            // the Jacobi / SpMV output is the next sweep's gathered source: keep it cacheable
+            store_d<R, NT && MODE == MODE_RESIDUAL>(a.out + row, o);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {

@@ -77,7 +77,8 @@ class DeviceHierarchy:
 
     def __init__(self, dim: int, coarsest_level: int, finest_level: int, c: int = 8, device: int = 0,
                  rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
-                 offset_codes: Optional[int] = None):
+                 offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
+                 nontemporal: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -93,6 +94,10 @@ class DeviceHierarchy:
             self.set_tuning("xcd_chunk", xcd_chunk)
         if offset_codes is not None:
             self.set_tuning("offset_codes", offset_codes)
+        if strip_slices is not None:
+            self.set_tuning("strip_slices", strip_slices)
+        if nontemporal is not None:
+            self.set_tuning("nontemporal", nontemporal)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):

@@ -417,3 +417,19 @@ def test_full_multigrid_solves_to_tolerance(mg, tmp_path, monkeypatch):
     rows = open(tmp_path / "iter_count_for_diff_num_elems_3_levels.csv").read().strip().split(",")
     assert rows == ["32", str(len(hist))]
     assert abs(mg.res_calculator(u, None) - np.linalg.norm(u)) <= 1e-12 * np.linalg.norm(u)
+
+
+def test_traversal_order_and_streaming_loads_do_not_change_results():
+    """XCD strip traversal (a different block -> slice bijection) and non-temporal loads are speed only."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    outs = []
+    for strips, nt, R in ((0, 0, 2), (8, 0, 2), (8, 1, 2), (4, 1, 1), (16, 1, 4), (64, 1, 2)):
+        with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=2, mu2=2, strip_slices=strips, nontemporal=nt,
+                                       rows_per_lane=R) as dev:             # 129^3 unknowns on the finest level
+            dev.zero_vector(4, "v")
+            res = dev.vcycle(4, 2, residuals=True)
+            outs.append((dev.get_vector(4, "v"), res, R))
+    for v, res, R in outs[1:]:
+        if R == outs[0][2]:
+            assert np.array_equal(v, outs[0][0])
+        assert rel_l2(v, outs[0][0]) <= 1e-13 and np.all(np.abs(res - outs[0][1]) <= 1e-12 * outs[0][1])
