@@ -137,6 +137,9 @@ struct Level {
 struct mg_context {
     int dim = 2, nlev = 0, device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;      // halo exchange overlapped with interior sweeps (world > 1)
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+    int overlap = 1;
     std::vector<Level> L;
     int mu1 = 50, mu2 = 50;
     double omega = 2.0 / 3.0;
@@ -371,18 +374,22 @@ void launch_ell_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hi
 
 // out = op(A, x) over all owned slices of the level
 int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
-               double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr) {
+               double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr,
+               int64_t slice0 = 0, int64_t slice_count = -1) {
+    if (slice_count < 0) slice_count = L.nslices - slice0;
+    if (slice_count == 0) return 0;
+    const bool whole = slice0 == 0 && slice_count == L.nslices;
     EllArgs a{};
     a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
-    a.slice0 = 0; a.nslices = L.nslices; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
+    a.slice0 = slice0; a.nslices = slice_count; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
-    unsigned grid = blocks_for(L.nslices, WAVES_PER_BLOCK);
+    unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
     if (L.coded) {
         // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
         const int64_t ps = ((L.g.plane / (WAVE * L.R)) / 4) * 4;
         const int ss = (c->strip_slices / 4) * 4;
-        if (ss > 0 && !dot && L.g.nz > 1 && ps >= 16 * (int64_t)ss && L.nslices < ((int64_t)1 << 31)) {
+        if (whole && ss > 0 && !dot && L.g.nz > 1 && ps >= 16 * (int64_t)ss && L.nslices < ((int64_t)1 << 31)) {
             a.strip_ss = (unsigned)ss;
             a.ps = (unsigned)ps;
             a.kp = (unsigned)((L.nslices + ps - 1) / ps);
@@ -425,7 +432,8 @@ int ensure_host_stage(mg_context* c, size_t elems) {
 
 // Fill both halo planes of `v` from the neighbouring slabs (first owned plane goes down,
 // last owned plane goes up).
-int exchange_halo(mg_context* c, const Level& L, DVector& v) {
+int exchange_halo(mg_context* c, const Level& L, DVector& v, hipStream_t stream = nullptr) {
+    if (!stream) stream = c->stream;
     Comm& cm = c->comm;
     if (L.replicated || !cm.active()) return 0;
     const size_t plane = (size_t)L.g.plane;
@@ -437,12 +445,12 @@ int exchange_halo(mg_context* c, const Level& L, DVector& v) {
     if (cm.nccl) {
         NCCL_TRY(g_rccl.GroupStart());
         if (lo) {
-            NCCL_TRY(g_rccl.Send(send_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, c->stream));
-            NCCL_TRY(g_rccl.Recv(recv_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, c->stream));
+            NCCL_TRY(g_rccl.Send(send_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Recv(recv_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, stream));
         }
         if (hi) {
-            NCCL_TRY(g_rccl.Send(send_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, c->stream));
-            NCCL_TRY(g_rccl.Recv(recv_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, c->stream));
+            NCCL_TRY(g_rccl.Send(send_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Recv(recv_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, stream));
         }
         NCCL_TRY(g_rccl.GroupEnd());
         return 0;
@@ -450,15 +458,15 @@ int exchange_halo(mg_context* c, const Level& L, DVector& v) {
     if (!cm.ex) return fail("no transport configured");
     MG_TRY(ensure_host_stage(c, 4 * plane));
     double* h = cm.h_stage;
-    if (lo) HIP_TRY(hipMemcpyAsync(h, send_lo, plane * 8, hipMemcpyDeviceToHost, c->stream));
-    if (hi) HIP_TRY(hipMemcpyAsync(h + plane, send_hi, plane * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (lo) HIP_TRY(hipMemcpyAsync(h, send_lo, plane * 8, hipMemcpyDeviceToHost, stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(h + plane, send_hi, plane * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     if (cm.ex(cm.user, lo ? h : nullptr, hi ? h + plane : nullptr, lo ? h + 2 * plane : nullptr,
               hi ? h + 3 * plane : nullptr, (int64_t)plane) != 0)
         return fail("exchange callback failed");
-    if (lo) HIP_TRY(hipMemcpyAsync(recv_lo, h + 2 * plane, plane * 8, hipMemcpyHostToDevice, c->stream));
-    if (hi) HIP_TRY(hipMemcpyAsync(recv_hi, h + 3 * plane, plane * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (lo) HIP_TRY(hipMemcpyAsync(recv_lo, h + 2 * plane, plane * 8, hipMemcpyHostToDevice, stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(recv_hi, h + 3 * plane, plane * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -525,10 +533,31 @@ DVector* pick(Level& L, int which) {
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
+    const bool dist = !L.replicated && c->comm.active();
+    // slices that hold rows of the first / last owned plane: their results are what the neighbours need
+    const int64_t S = (int64_t)WAVE * L.R;
+    const int64_t lo_end = std::min(L.nslices, (L.g.plane + S - 1) / S);
+    const int64_t hi_begin = std::max<int64_t>(lo_end, (L.nloc - L.g.plane) / S);
+    const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream;
     for (int s = 0; s < nw; ++s) {
-        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
+        if (!overlap) {
+            MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
+            std::swap(L.v, L.v2);
+            MG_TRY(exchange_halo(c, L, L.v));
+            continue;
+        }
+        // boundary planes first, then their exchange on the communication stream while the interior runs
+        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
+        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
+                          L.nslices - hi_begin));
+        HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+        MG_TRY(exchange_halo(c, L, L.v2, c->comm_stream));
+        HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, lo_end,
+                          hi_begin - lo_end));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
         std::swap(L.v, L.v2);
-        MG_TRY(exchange_halo(c, L, L.v));
     }
     return 0;
 }
@@ -831,6 +860,9 @@ int mg_create(int n_levels, int dim, int device, mg_handle* out) {
     c->L.resize(n_levels);
     HIP_TRY(hipGetDeviceProperties(&c->prop, device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
     MG_TRY(dev_alloc(c, &c->partials, 2 * kMaxParts));
     MG_TRY(dev_alloc(c, &c->scalars, 8));
     MG_TRY(dev_alloc(c, &c->done, 1));
@@ -858,6 +890,9 @@ int mg_destroy(mg_handle c) {
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->comm.h_stage) (void)hipHostFree(c->comm.h_stage);
     if (c->comm.nccl) g_rccl.CommDestroy(c->comm.nccl);
+    if (c->ev_boundary) (void)hipEventDestroy(c->ev_boundary);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -982,6 +1017,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->strip_slices = (int)value;
     } else if (k == "nontemporal") {
         c->nontemporal = value != 0;
+    } else if (k == "overlap") {
+        c->overlap = value != 0;
     } else if (k == "pcg_chunk") {
         if (value < 1) return fail("pcg_chunk must be positive");
         c->pcg_chunk = (int)value;
