@@ -387,15 +387,19 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
     if (L.coded) {
         // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
-        const int64_t ps = ((L.g.plane / (WAVE * L.R)) / 4) * 4;
-        const int ss = (c->strip_slices / 4) * 4;
-        if (whole && ss > 0 && !dot && L.g.nz > 1 && ps >= 16 * (int64_t)ss && L.nslices < ((int64_t)1 << 31)) {
-            a.strip_ss = (unsigned)ss;
-            a.ps = (unsigned)ps;
-            a.kp = (unsigned)((L.nslices + ps - 1) / ps);
-            const int64_t strips = (ps + ss - 1) / ss;
-            const int64_t g = 8 * ((strips + 7) / 8) * (int64_t)a.kp * (ss / 4);
-            if (g < ((int64_t)1 << 31)) grid = (unsigned)g; else a.strip_ss = 0;
+        const int64_t ps4 = (L.g.plane / (WAVE * L.R)) / 4;            // blocks per pseudo-plane
+        const int64_t want = c->strip_slices / 4;                       // blocks per strip asked for
+        if (whole && want > 0 && !dot && L.g.nz > 1 && ps4 >= 16 * want) {
+            const int64_t m = std::max<int64_t>(1, (ps4 + 4 * want) / (8 * want));     // round(ps4 / want / 8)
+            const int64_t ns = 8 * m;
+            const int64_t nblocks = (L.nslices + 3) / 4;
+            const int64_t kp = (nblocks + ps4 - 1) / ps4;
+            const int64_t bmax = (ps4 + ns - 1) / ns;
+            const int64_t g = ns * kp * bmax;
+            if (g < ((int64_t)1 << 31) && kp < ((int64_t)1 << 31)) {
+                a.strip_ns = (unsigned)ns; a.strip_bmax = (unsigned)bmax; a.ps4 = (unsigned)ps4; a.kp = (unsigned)kp;
+                grid = (unsigned)g;
+            }
         }
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;

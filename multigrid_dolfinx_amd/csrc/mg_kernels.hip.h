@@ -104,9 +104,10 @@ struct EllArgs {
     const int* offsets;
     int ntable;
     int dcode;              // code of offset 0 (the diagonal / padding)
-    // XCD strip traversal (0 = chunked map): see strip_block()
-    unsigned strip_ss;      // slices per strip (multiple of 4)
-    unsigned ps;            // slices per pseudo-plane (multiple of 4)
+    // XCD strip traversal (strip_ns == 0: chunked map): see strip_block()
+    unsigned strip_ns;      // strips per pseudo-plane, a multiple of 8 (one share per XCD)
+    unsigned strip_bmax;    // blocks (4 slices each) in the widest strip
+    unsigned ps4;           // blocks per pseudo-plane
     unsigned kp;            // pseudo-planes
 };
 
@@ -115,20 +116,21 @@ struct EllArgs {
 // 4 MiB XCD L2, so with a plane-by-plane sweep every x line is pulled across the fabric ~4 times.
 // Here each XCD instead walks a STRIP of ~8 grid lines through all planes: the slices are viewed as
 // pseudo-planes of `ps` slices (the plane size rounded to whole slices; the ~1-row drift per plane
-// only blurs locality), a strip is `strip_ss` consecutive slices of a pseudo-plane, strips are dealt
-// to the 8 XCDs (s % 8), and the blocks of one XCD (blockIdx % 8, dealt round-robin by the dispatcher)
-// enumerate (strip, plane, block-in-strip) with the plane index fastest.  The three x planes a strip
-// touches at step k (~64 KB each) are then still in that XCD's L2 at steps k+1 and k+2.  It is a
-// bijection on slices whatever the dispatcher does: placement changes speed only.
+// only blurs locality); every pseudo-plane is cut into `strip_ns` = 8m strips of (almost) equal width,
+// strip s belongs to XCD s % 8 -- every XCD gets exactly m strips, so there is no tail -- and the blocks
+// of one XCD (blockIdx % 8, dealt round-robin by the dispatcher) enumerate (strip, plane,
+// block-in-strip) with the plane index fastest.  The three x planes a strip touches at step k
+// (~64 KB each) are then still in that XCD's L2 at steps k+1 and k+2.  It is a bijection on slices
+// whatever the dispatcher does: placement changes speed only.
 // Returns the first slice of the block's 4-slice group, or -1 for a padding block.
 __device__ __forceinline__ int64_t strip_block(const EllArgs& a, unsigned b) {
     const unsigned x = b & 7u, q = b >> 3;
-    const unsigned bpt = a.strip_ss >> 2;
-    const unsigned bi = q % bpt, t = q / bpt;
-    const unsigned k = t % a.kp, sx = t / a.kp;
-    const unsigned in_plane = (sx * 8u + x) * a.strip_ss + bi * 4u;
-    if (in_plane >= a.ps) return -1;
-    return (int64_t)k * a.ps + in_plane;
+    const unsigned bi = q % a.strip_bmax, t = q / a.strip_bmax;
+    const unsigned k = t % a.kp, s = (t / a.kp) * 8u + x;
+    const unsigned lo = (unsigned)(((unsigned long long)s * a.ps4) / a.strip_ns);
+    const unsigned hi = (unsigned)(((unsigned long long)(s + 1) * a.ps4) / a.strip_ns);
+    if (bi >= hi - lo) return -1;
+    return ((int64_t)k * a.ps4 + lo + bi) * 4;
 }
 
 typedef double dvec2_t __attribute__((ext_vector_type(2)));
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     int64_t sl;
-    if (a.strip_ss) {
+    if (a.strip_ns) {
         const int64_t first = strip_block(a, blockIdx.x);
         if (!DOT && first < 0) return;
         sl = first < 0 ? a.nslices : first + wave;

@@ -322,7 +322,8 @@ def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c):
 
 
 # ---- size-independent properties at larger sizes ----------------------------------------------------------------------------
-@pytest.mark.parametrize("dim,lo,hi", [(2, 3, 7), (3, 2, 4)])        # 1024x1024 (5 levels); 128^3 (3 levels)
+# 1024x1024 (5 levels); 128^3 (3 levels); BASELINE configs C2 = 2048x2048, 5 levels and C3 = 256^3, 4 levels
+@pytest.mark.parametrize("dim,lo,hi", [(2, 3, 7), (3, 2, 4), (2, 4, 8), (3, 2, 5)])
 def test_properties_at_scale(dim, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     with DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=2, mu2=2) as dev:
@@ -433,3 +434,24 @@ def test_traversal_order_and_streaming_loads_do_not_change_results():
         if R == outs[0][2]:
             assert np.array_equal(v, outs[0][0])
         assert rel_l2(v, outs[0][0]) <= 1e-13 and np.all(np.abs(res - outs[0][1]) <= 1e-12 * outs[0][1])
+
+
+def test_headline_size_checksums_agree_between_formats():
+    """BASELINE config C4 at full size (1025^3 unknowns, 6 levels, one GPU).  Vectors of this size never
+    cross to the host; the check is a checksum of checksums: the l2 residual norms of three V(2,2) cycles
+    must fall monotonically and agree between the two matrix formats (offset-coded columns with in-kernel
+    D^-1 vs int32 columns with streamed D^-1), which share nothing but the arithmetic."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    norms = []
+    for codes in (1, 0):
+        with DeviceHierarchy.synthetic(3, 2, 7, c=8, mu1=2, mu2=2, offset_codes=codes) as dev:
+            info = dev.level_info(7)
+            assert info["n_global"] == 1025 ** 3 and info["ell_width"] == 7
+            assert (info["offset_codes"] == 7) == bool(codes)
+            assert info["nnz_nonzero"] == 7 * 1023 ** 3 - 6 * 1023 ** 2 + (1025 ** 3 - 1023 ** 3)
+            f_norm = dev.norm2(7, "f")
+            dev.zero_vector(7, "v")
+            res = dev.vcycle(7, 3, residuals=True)
+            assert res[0] < f_norm and res[1] < res[0] and res[2] < res[1]
+            norms.append(np.concatenate([[f_norm], res]))
+    assert np.all(np.abs(norms[0] - norms[1]) <= 1e-12 * norms[1])
