@@ -50,7 +50,11 @@ enum mg_restriction {
 };
 
 enum mg_smoother {
-    MG_SMOOTH_JACOBI = 0            /* jacobiRelaxation, multigrid.py:223-228 */
+    MG_SMOOTH_JACOBI = 0,           /* jacobiRelaxation, multigrid.py:223-228 */
+    MG_SMOOTH_RBGS = 1              /* red-black Gauss-Seidel / SOR with factor omega (no reference;
+                                       BASELINE.json config 5): per sweep one in-place half sweep per
+                                       colour, colour = parity of the lexicographic node index.  Needs
+                                       pruned grid matrices (P1 stencils are then bipartite). */
 };
 
 /* ---- life cycle ----------------------------------------------------------------

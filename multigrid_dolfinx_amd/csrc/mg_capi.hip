@@ -124,6 +124,7 @@ struct Level {
     int* offsets = nullptr;
     int ntable = 0, dcode = 0;
     bool coded = false;
+    bool rb_ok = false;                     // index parity is a valid red-black colouring of the matrix
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
     int* perm = nullptr;
@@ -308,6 +309,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * (WAVE * L.R));
     dev_free(c, L.offsets, 256);
     L.coded = false;
+    L.rb_ok = false;
     dev_free(c, L.dinv, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.perm, (size_t)L.n_global);
     vec_free(c, L, &L.v);
@@ -326,6 +328,8 @@ void launch_ell_wr(int mode, bool dot, const EllArgs& a, unsigned grid, hipStrea
         hipLaunchKernelGGL((ell_apply<WT, R, MODE_RESIDUAL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_JACOBI)
         hipLaunchKernelGGL((ell_apply<WT, R, MODE_JACOBI, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_GS)
+        hipLaunchKernelGGL((ell_apply<WT, R, MODE_GS, false>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (dot)
         hipLaunchKernelGGL((ell_apply<WT, R, MODE_SPMV, true>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
@@ -338,6 +342,8 @@ void launch_ell_coded_wrn(int mode, bool dot, const EllArgs& a, unsigned grid, h
         hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_JACOBI)
         hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_GS)
+        hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (dot)
         hipLaunchKernelGGL((ell_apply_coded<WT, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
@@ -375,7 +381,7 @@ void launch_ell_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hi
 // out = op(A, x) over all owned slices of the level
 int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
                double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr,
-               int64_t slice0 = 0, int64_t slice_count = -1) {
+               int64_t slice0 = 0, int64_t slice_count = -1, int color = 0) {
     if (slice_count < 0) slice_count = L.nslices - slice0;
     if (slice_count == 0) return 0;
     const bool whole = slice0 == 0 && slice_count == L.nslices;
@@ -384,6 +390,7 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
     a.slice0 = slice0; a.nslices = slice_count; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
+    a.color = color; a.parity0 = (int)(L.row0 & 1);
     unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
     if (L.coded) {
         // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
@@ -537,6 +544,18 @@ DVector* pick(Level& L, int which) {
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
+    if (c->smoother == MG_SMOOTH_RBGS) {
+        // red-black Gauss-Seidel: two in-place half sweeps per sweep, halos refreshed after each colour
+        if (!L.rb_ok)
+            return fail("red-black ordering is not a valid two-colouring of level " + std::to_string(level) +
+                        " (needs a pruned grid matrix with an odd number of nodes per axis)");
+        for (int s = 0; s < nw; ++s)
+            for (int color = 0; color < 2; ++color) {
+                MG_TRY(launch_ell(c, L, MODE_GS, false, L.v.base, L.f.rows, L.v.rows, nullptr, nullptr, nullptr, 0, -1, color));
+                MG_TRY(exchange_halo(c, L, L.v));
+            }
+        return 0;
+    }
     const bool dist = !L.replicated && c->comm.active();
     // slices that hold rows of the first / last owned plane: their results are what the neighbours need
     const int64_t S = (int64_t)WAVE * L.R;
@@ -771,6 +790,9 @@ int encode_level(mg_context* c, Level& L) {
     if (zero == offs.end()) return fail("offset table lacks the diagonal");
     L.ntable = (int)offs.size();
     L.dcode = (int)(zero - offs.begin());
+    L.rb_ok = !L.flat && (L.g.nx & 1) && (L.g.ny & 1);
+    for (int o : offs)
+        if (o != 0 && (o & 1) == 0) L.rb_ok = false;       // a coupling inside one colour
     offs.resize(256, 0);
     MG_TRY(dev_alloc(c, &L.offsets, 256));
     HIP_TRY(hipMemcpyAsync(L.offsets, offs.data(), 256 * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -993,7 +1015,7 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
     if (!c) return fail("null handle");
     if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
     if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
-    if (smoother != MG_SMOOTH_JACOBI) return fail("unknown smoother");
+    if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS) return fail("unknown smoother");
     c->mu1 = mu1; c->mu2 = mu2; c->omega = omega; c->restriction = restriction; c->smoother = smoother;
     if (coarse_rtol > 0) c->coarse_rtol = coarse_rtol;
     if (coarse_maxit > 0) c->coarse_maxit = coarse_maxit;

@@ -35,7 +35,10 @@ template <int R> struct alignas(8 * R) DVec { double d[R]; };
 template <int R> struct alignas(4 * R) IVec { int d[R]; };
 template <int R> struct alignas(8 * R) UVec { unsigned long long d[R]; };
 
-enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
+// MODE_GS: in-place relaxation of the rows of one colour (red-black Gauss-Seidel half sweep);
+// the colour of a row is the parity of its global lexicographic index, a valid two-colouring of
+// the pruned P1 stencils on grids with an odd number of nodes per axis.
+enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2, MODE_GS = 3 };
 
 // Geometry of one level's (slab of the) grid.  2-D grids are stored as (nx, 1, nz).
 struct Grid {
@@ -105,6 +108,8 @@ struct EllArgs {
     int ntable;
     int dcode;              // code of offset 0 (the diagonal / padding)
     // XCD strip traversal (strip_ns == 0: chunked map): see strip_block()
+    int color;              // MODE_GS: colour relaxed by this launch
+    int parity0;            // MODE_GS: parity of the global index of local row 0
     unsigned strip_ns;      // strips per pseudo-plane, a multiple of 8 (one share per XCD)
     unsigned strip_bmax;    // blocks (4 slices each) in the widest strip
     unsigned ps4;           // blocks per pseudo-plane
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
             }
         }
         DVec<R> o;
-        if (row + R <= a.nloc) {
+        if (MODE != MODE_GS && row + R <= a.nloc) {
             if (MODE == MODE_SPMV) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) o.d[r] = acc[r];
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t rr = row + r;
+                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
                 if (rr < a.nloc) {
                     double val;
                     if (MODE == MODE_SPMV) {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply(EllArgs a) {
             }
         }
         DVec<R> o;
-        if (row + R <= a.nloc) {
+        if (MODE != MODE_GS && row + R <= a.nloc) {
             if (MODE == MODE_SPMV) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) o.d[r] = acc[r];
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply(EllArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t rr = row + r;
+                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
                 if (rr < a.nloc) {
                     double val;
                     if (MODE == MODE_SPMV) {

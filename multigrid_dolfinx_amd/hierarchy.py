@@ -204,10 +204,11 @@ class DeviceHierarchy:
                                              1 if prune_zeros else 0))
 
     def set_params(self, mu1: int, mu2: int, omega: float, restriction: str = "direct",
-                   coarse_rtol: float = 1e-14, coarse_maxit: int = 20000, keep_err: bool = False):
+                   coarse_rtol: float = 1e-14, coarse_maxit: int = 20000, keep_err: bool = False,
+                   smoother: str = "jacobi"):
+        sm = {"jacobi": _capi.MG_SMOOTH_JACOBI, "rbgs": _capi.MG_SMOOTH_RBGS}[smoother]
         check(self._lib.mg_set_params(self._h, int(mu1), int(mu2), float(omega), _RESTRICT[restriction],
-                                      _capi.MG_SMOOTH_JACOBI, float(coarse_rtol), int(coarse_maxit),
-                                      1 if keep_err else 0))
+                                      sm, float(coarse_rtol), int(coarse_maxit), 1 if keep_err else 0))
 
     @classmethod
     def from_bag(cls, bag, dim: int = 2, grid_index: Optional[Dict[int, np.ndarray]] = None,

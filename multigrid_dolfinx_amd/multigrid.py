@@ -49,7 +49,8 @@ u_exact_fine = None
 V_fine_dolfx = None
 
 # ---- state of this implementation --------------------------------------------------------------------
-_options = {"dim": 2, "prune_zeros": True, "device": 0, "restriction": "direct", "grid_index": None,
+_options = {"dim": 2, "prune_zeros": True, "device": 0, "restriction": "direct", "smoother": "jacobi",
+            "grid_index": None,
             "coarse_rtol": 1e-14, "stop_tol": 1e-11, "max_cycles": 10000, "tuning": {}}
 _hier = None            # DeviceHierarchy of the initialised problem
 _grid_cache = {}        # id(mesh dict) -> (dict, grid_index, N)
@@ -58,7 +59,8 @@ _adhoc = {}             # small cache of stand-alone device contexts (transfers 
 
 def configure(**kw):
     """Options with no reference counterpart: `dim` (2 or 3), `prune_zeros`, `device`,
-    `restriction` ('direct' = the live path, or 'full_weighting'), `grid_index`
+    `restriction` ('direct' = the live path, or 'full_weighting'), `smoother` ('jacobi' = the
+    reference's, or 'rbgs' = red-black Gauss-Seidel with `omega` as SOR factor), `grid_index`
     ({level: lexicographic node index per DoF}, instead of coordinate dictionaries),
     `coarse_rtol`, `stop_tol`, `max_cycles`, `tuning` (kernel knobs)."""
     global _hier
@@ -132,7 +134,7 @@ def _hierarchy():
             h.set_level(level, A_sp_dict[level][0], gi, prune_zeros=_options["prune_zeros"])
         _hier = h
     _hier.set_params(mu1, mu2, omega, restriction=_options["restriction"],
-                     coarse_rtol=_options["coarse_rtol"], keep_err=True)
+                     coarse_rtol=_options["coarse_rtol"], keep_err=True, smoother=_options["smoother"])
     return _hier
 
 

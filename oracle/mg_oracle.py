@@ -37,7 +37,7 @@ import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.linalg import spsolve
 
-__all__ = ["get_jacobi_matrices", "jacobi_relaxation", "Oracle"]
+__all__ = ["get_jacobi_matrices", "jacobi_relaxation", "rbgs_relaxation", "Oracle"]
 
 
 def get_jacobi_matrices(A_and_level):
@@ -58,6 +58,20 @@ def jacobi_relaxation(A_jac, v, f, nw, omega):
     DinvR, Dinv = A_jac[0], A_jac[1]
     for _ in range(nw):
         v = (1 - omega) * v + omega * Dinv.dot(f) - omega * DinvR.dot(v)
+    return v
+
+
+def rbgs_relaxation(A, v, f, nw, omega, color):
+    """`nw` red-black Gauss-Seidel (SOR factor `omega`) sweeps: per sweep, rows of colour 0 then rows of
+    colour 1 are relaxed in place, `v_i += omega (f_i - (A v)_i) / a_ii`.  NO REFERENCE COUNTERPART
+    (BASELINE.json config 5 names the smoother; the reference only has Jacobi): parity unpinned."""
+    v = np.array(v, dtype=np.float64, copy=True)
+    d_inv = 1.0 / A.diagonal()
+    rows = [np.flatnonzero(color == c) for c in (0, 1)]
+    parts = [A[r, :] for r in rows]
+    for _ in range(nw):
+        for r, Ar in zip(rows, parts):
+            v[r, 0] = v[r, 0] + omega * d_inv[r] * (f[r, 0] - Ar.dot(v[:, 0]))
     return v
 
 
@@ -184,7 +198,13 @@ class Oracle:
         u = spsolve(self.A_sp_dict[self.coarsest_level][0], f_h)
         return np.array(u).reshape(len(u), 1)
 
-    def v_cycle(self, A_h, v_h, f_h, test=False, restriction="direct"):
+    def smooth(self, A_h, v, f, nw, smoother):
+        if smoother == "jacobi":
+            return jacobi_relaxation(A_h, v, f, nw, self.omega)
+        level = A_h[2]
+        return rbgs_relaxation(self.A_sp_dict[level][0], v, f, nw, self.omega, self.grid_index[level] & 1)
+
+    def v_cycle(self, A_h, v_h, f_h, test=False, restriction="direct", smoother="jacobi"):
         """One recursive V(mu1, mu2) cycle; follows `multigrid.py:231-268`.
 
         The smoother uses the argument `A_h`, the residual and the coarsest solve use
@@ -194,17 +214,17 @@ class Oracle:
         level = A_h[2]
         if level == self.coarsest_level:
             return self.coarse_solve(f_h)
-        v_h = jacobi_relaxation(A_h, v_h, f_h, self.mu1, self.omega)
+        v_h = self.smooth(A_h, v_h, f_h, self.mu1, smoother)
         r_h = f_h - self.A_sp_dict[level][0].dot(v_h)
         if restriction == "direct":
             f_2h = self.restrict_direct(r_h, level)
         else:
             f_2h = self.restrict_full_weighting(r_h, level)
         v_2h = np.zeros((f_2h.shape[0], 1))
-        v_2h = self.v_cycle(self.A_jacobi_sp_dict[level - 1], v_2h, f_2h, test, restriction)
+        v_2h = self.v_cycle(self.A_jacobi_sp_dict[level - 1], v_2h, f_2h, test, restriction, smoother)
         err_h = self.interpolate(v_2h, level - 1)
         v_h = v_h + err_h
-        v_h = jacobi_relaxation(A_h, v_h, f_h, self.mu2, self.omega)
+        v_h = self.smooth(A_h, v_h, f_h, self.mu2, smoother)
         if test and level == self.finest_level:
             return v_h, f_2h, v_2h, err_h
         return v_h

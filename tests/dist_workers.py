@@ -113,6 +113,12 @@ def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode
             h.fmg(2)
         assert np.array_equal(par.get_vector(hi, "v", gather=True), ser.get_vector(hi, "v"))
         assert abs(par.norm2(hi, "v") - ser.norm2(hi, "v")) <= 1e-13 * ser.norm2(hi, "v")
+        # red-black Gauss-Seidel: colours follow the GLOBAL index parity in every slab
+        for h in (par, ser):
+            h.set_params(mu, mu, 1.0, smoother="rbgs")
+            h.zero_vector(hi, "v")
+            h.vcycle(hi, 1)
+        assert np.array_equal(par.get_vector(hi, "v", gather=True), ser.get_vector(hi, "v"))
         par.close()
         ser.close()
     finally:

@@ -455,3 +455,40 @@ def test_headline_size_checksums_agree_between_formats():
             assert res[0] < f_norm and res[1] < res[0] and res[2] < res[1]
             norms.append(np.concatenate([[f_norm], res]))
     assert np.all(np.abs(norms[0] - norms[1]) <= 1e-12 * norms[1])
+
+
+@pytest.mark.parametrize("dim,lo,hi,c,seed", [(2, 1, 3, 8, 4), (3, 1, 3, 2, None), (3, 1, 3, 4, 6)])
+def test_red_black_gauss_seidel_matches_oracle(dim, lo, hi, c, seed):
+    """BASELINE config 5's smoother (no reference implementation: parity unpinned, oracle only)."""
+    from multigrid_dolfinx_amd._capi import MgError
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle, rbgs_relaxation
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, seed=seed)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    orc = Oracle(bag, gi, dim=dim)
+    rng = np.random.default_rng(5)
+    f = bag.b_dict[hi]
+    v0 = rng.standard_normal(f.shape)
+    for R in (1, 2, 4):
+        with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, rows_per_lane=R) as dev:
+            for omega in (1.0, 1.2):
+                dev.set_params(2, 2, omega, smoother="rbgs")
+                dev.set_vector(hi, "v", v0)
+                dev.set_vector(hi, "f", f)
+                dev.smooth(hi, 3)
+                want = rbgs_relaxation(bag.A_sp_dict[hi][0], v0, f, 3, omega, gi[hi] & 1)
+                assert rel_l2(dev.get_vector(hi, "v"), want) <= TOL_SWEEP
+            dev.set_params(2, 2, 1.0, smoother="rbgs")
+            want = orc.v_cycle(orc.A_jacobi_sp_dict[hi], np.zeros_like(f), f, smoother="rbgs")
+            assert rel_l2(_one_cycle(dev, hi, f), want) <= TOL_ITER
+            # Gauss-Seidel smooths better than the reference's damped Jacobi at equal sweep counts
+            res_gs = dev.vcycle(hi, 1, residuals=True)[0]
+            dev.set_params(2, 2, 2.0 / 3.0, smoother="jacobi")
+            dev.zero_vector(hi, "v")
+            res_j = dev.vcycle(hi, 2, residuals=True)[1]
+            assert res_gs < res_j
+    # as-delivered matrices keep the same-colour (zero) couplings: the colouring is refused
+    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=False) as dev:
+        dev.set_params(1, 1, 1.0, smoother="rbgs")
+        with pytest.raises(MgError, match="two-colouring"):
+            dev.smooth(hi, 1)

@@ -161,3 +161,24 @@ def test_interpolation_reproduces_multilinear_and_injection_is_exact():
         for d in range(dim):
             interior &= (h.levels[0].coords[:, d] > 0) & (h.levels[0].coords[:, d] < 1)
         assert np.allclose(fw[interior], 1.0)
+
+
+def test_rbgs_oracle_against_plain_loops():
+    """Red-black Gauss-Seidel has no reference counterpart; pin the vectorised oracle to a scalar loop."""
+    from multigrid_dolfinx_amd import poisson
+    from oracle.mg_oracle import rbgs_relaxation
+    for dim, N in ((2, 6), (3, 4)):
+        L = poisson.make_level(N, dim, seed=2, keep_zeros=False)
+        A = L.A.toarray()
+        color = L.grid_index & 1
+        rng = np.random.default_rng(0)
+        v0 = rng.standard_normal((L.n, 1))
+        got = rbgs_relaxation(L.A, v0, L.b, 2, 1.15, color)
+        v = v0.copy()
+        for _ in range(2):
+            for c in (0, 1):
+                for i in np.flatnonzero(color == c):
+                    assert all(color[j] != c for j in np.flatnonzero(A[i]) if j != i)    # bipartite
+                    v[i, 0] += 1.15 * (L.b[i, 0] - A[i] @ v[:, 0]) / A[i, i]
+        assert np.abs(got - v).max() <= 1e-13
+        assert np.array_equal(v0, v0)
