@@ -691,9 +691,8 @@ int coarse_solve(mg_context* c, int* iters_out, double* rel_out) {
         for (int b = 0; b < batch; ++b) {
             unsigned np_spmv = 0;
             MG_TRY(launch_ell(c, L, MODE_SPMV, true, c->pcg_p.base, nullptr, c->pcg_q, c->pcg_part_a, c->done, &np_spmv));
-            hipLaunchKernelGGL(pcg_update, grid, blk, 0, c->stream, a, (int)np_spmv);
-            hipLaunchKernelGGL(pcg_direction, grid, blk, 0, c->stream, a);
-            hipLaunchKernelGGL(pcg_scalars, dim3(1), blk, 0, c->stream, a);
+            hipLaunchKernelGGL(pcg_update, grid, blk, 0, c->stream, a, (int)np_spmv, it + b);
+            hipLaunchKernelGGL(pcg_direction, grid, blk, 0, c->stream, a, it + b);
         }
         it += batch;
         HIP_TRY(hipGetLastError());

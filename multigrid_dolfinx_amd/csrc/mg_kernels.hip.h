@@ -738,7 +738,9 @@ __global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restric
 }
 
 // ---- coarsest-level solver: Jacobi-preconditioned CG, scalars kept on the device -------------------
-// Scalars: sc[0]=rz, sc[1]=pq, sc[2]=rr, sc[3]=bb, sc[4]=rz_new, sc[5]=iterations
+// Scalars: sc[0], sc[1] = r.z of even / odd iterations (double-buffered so that the kernel which
+// computes the new value can still hand the old one to all of its blocks), sc[2]=rr, sc[3]=bb,
+// sc[5]=iterations done.
 struct PcgArgs {
     double* x; double* r; double* z; double* p; double* q;   // row-based (p is stored with halo lead)
     const double* b; const double* dinv;
@@ -753,7 +755,9 @@ __device__ __forceinline__ double sum_partials(const double* part, int np) {
     const double r = block_sum(s);
     if (threadIdx.x == 0) s_tot = r;
     __syncthreads();
-    return s_tot;
+    const double out = s_tot;
+    __syncthreads();
+    return out;
 }
 
 // x = 0, r = b, z = D^-1 r, p = z; partial r.z -> part_a, b.b -> part_b
@@ -774,17 +778,17 @@ __global__ __launch_bounds__(BLOCK) void pcg_init_finish(PcgArgs a) {
     const double rz = sum_partials(a.part_a, a.nparts);
     const double bb = sum_partials(a.part_b, a.nparts);
     if (threadIdx.x == 0) {
-        a.sc[0] = rz; a.sc[3] = bb; a.sc[2] = bb; a.sc[5] = 0.0;
+        a.sc[0] = rz; a.sc[1] = rz; a.sc[3] = bb; a.sc[2] = bb; a.sc[5] = 0.0;
         *a.done = (bb == 0.0) ? 1 : 0;
     }
 }
 
-// after q = A p (partials of p.q in part_a, np_spmv of them):
+// after q = A p (partials of p.q in part_a, np_spmv of them), iteration `it`:
 // alpha = rz/pq; x += alpha p; r -= alpha q; z = D^-1 r; partials r.z -> part_b[0..), r.r -> part_b[nparts..)
-__global__ __launch_bounds__(BLOCK) void pcg_update(PcgArgs a, int np_spmv) {
+__global__ __launch_bounds__(BLOCK) void pcg_update(PcgArgs a, int np_spmv, int it) {
     if (*a.done) return;
     const double pq = sum_partials(a.part_a, np_spmv);
-    const double alpha = a.sc[0] / pq;
+    const double alpha = a.sc[it & 1] / pq;
     double rz = 0.0, rr = 0.0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * blockDim.x) {
         a.x[t] = fma(alpha, a.p[t], a.x[t]);
@@ -798,23 +802,22 @@ __global__ __launch_bounds__(BLOCK) void pcg_update(PcgArgs a, int np_spmv) {
     if (threadIdx.x == 0) { a.part_b[blockIdx.x] = s1; a.part_b[a.nparts + blockIdx.x] = s2; }
 }
 
-// beta = rz_new/rz; p = z + beta p; bookkeeping and convergence flag (single extra block does the scalars)
-__global__ __launch_bounds__(BLOCK) void pcg_direction(PcgArgs a) {
+// beta = rz_new/rz_old; p = z + beta p.  Every block reduces the partials itself; block 0 also publishes
+// rz_new into the OTHER scalar slot (nobody reads that slot in this launch), the iteration count and the
+// convergence flag.  A block that starts after the flag was raised skips its part of p, which is
+// harmless: x is final once the flag is up.
+__global__ __launch_bounds__(BLOCK) void pcg_direction(PcgArgs a, int it) {
     if (*a.done) return;
     const double rz_new = sum_partials(a.part_b, a.nparts);
-    const double beta = rz_new / a.sc[0];
+    const double beta = rz_new / a.sc[it & 1];
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * blockDim.x)
         a.p[t] = fma(beta, a.p[t], a.z[t]);
-}
-
-// runs after pcg_direction (separate launch so every block saw the old rz)
-__global__ __launch_bounds__(BLOCK) void pcg_scalars(PcgArgs a) {
-    if (*a.done) return;
-    const double rz_new = sum_partials(a.part_b, a.nparts);
-    const double rr = sum_partials(a.part_b + a.nparts, a.nparts);
-    if (threadIdx.x == 0) {
-        a.sc[0] = rz_new; a.sc[2] = rr; a.sc[5] += 1.0;
-        if (rr <= a.rtol2 * a.sc[3]) *a.done = 1;
+    if (blockIdx.x == 0) {
+        const double rr = sum_partials(a.part_b + a.nparts, a.nparts);
+        if (threadIdx.x == 0) {
+            a.sc[(it + 1) & 1] = rz_new; a.sc[2] = rr; a.sc[5] += 1.0;
+            if (rr <= a.rtol2 * a.sc[3]) *a.done = 1;
+        }
     }
 }
 
