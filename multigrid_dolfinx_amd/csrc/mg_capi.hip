@@ -3,6 +3,7 @@
 // handle's stream; all arithmetic of the path runs in the kernels of mg_kernels.hip.h.
 #include "../../include/mg_hip.h"
 #include "mg_kernels.hip.h"
+#include "mg_direct.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -135,6 +136,16 @@ struct Level {
 
 }  // namespace
 
+// Block-tridiagonal LU of the coarsest level (mg_direct.hip.h)
+struct DirectSolver {
+    bool tried = false, ok = false;
+    BtGeom g{};
+    double* T = nullptr;                    // nb dense p x p inverses of the Schur complements
+    int *lcol = nullptr, *ucol = nullptr;   // couplings, nb * p * W each
+    double *lval = nullptr, *uval = nullptr;
+    double *y = nullptr, *x = nullptr, *w = nullptr;
+};
+
 struct mg_context {
     int dim = 2, nlev = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -164,6 +175,8 @@ struct mg_context {
     DVector pcg_p;
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
+    int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
+    DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
     int64_t bytes = 0;
@@ -301,7 +314,10 @@ int alloc_level_vectors(mg_context* c, Level& L) {
     return 0;
 }
 
+void free_direct(mg_context* c);
+
 void free_level(mg_context* c, Level& L) {
+    if (&L == &c->L[0]) free_direct(c);
     if (!L.set && !L.vals) return;
     const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
     dev_free(c, L.vals, ell);
@@ -658,10 +674,118 @@ int norm2(mg_context* c, const Level& L, const double* x_rows, double* out) {
     return 0;
 }
 
-// Coarsest level: v = A^-1 f by Jacobi-preconditioned CG run to `coarse_rtol`; stands in for the
-// reference's exact spsolve (multigrid.py:239-241).  Iterations are enqueued in batches; only the
-// 4-byte convergence flag crosses to the host between batches.
+void free_direct(mg_context* c) {
+    DirectSolver& d = c->direct;
+    const size_t pw = (size_t)d.g.nb * d.g.p * (d.g.W > 0 ? d.g.W : 1), np = (size_t)d.g.nb * d.g.p;
+    dev_free(c, d.T, np * d.g.p);
+    dev_free(c, d.lcol, pw); dev_free(c, d.ucol, pw); dev_free(c, d.lval, pw); dev_free(c, d.uval, pw);
+    dev_free(c, d.y, np); dev_free(c, d.x, np); dev_free(c, d.w, (size_t)d.g.p);
+    d = DirectSolver();
+}
+
+EllView ell_view(const Level& L) {
+    EllView e{};
+    e.vals = L.vals; e.cols = L.cols; e.codes = L.codes; e.offsets = L.offsets;
+    e.W = L.W; e.R = L.R; e.coded = L.coded ? 1 : 0; e.n = L.nloc;
+    return e;
+}
+
+// Factor the coarsest level once: T_k = (D_k - L_k T_{k-1} U_{k-1})^-1 for every block of planes.
+int build_direct(mg_context* c) {
+    DirectSolver& d = c->direct;
+    d.tried = true;
+    Level& L = c->L[0];
+    if (!c->use_direct || L.flat || L.g.lead != 0) return 0;
+    const int64_t plane = L.g.plane;
+    const int nz = L.g.nz;
+    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(nz, (512 + plane - 1) / plane));
+    const int64_t p = G * plane;
+    const int64_t nb = (nz + G - 1) / G;
+    if (p > 2048 || nb * p * p * 8 > ((int64_t)3 << 29)) return 0;     // too large to store densely: PCG
+    d.g.n = L.nloc; d.g.p = (int)p; d.g.plane = (int)plane; d.g.nb = (int)nb; d.g.W = L.W;
+    const size_t pw = (size_t)nb * p * L.W, np = (size_t)nb * p, pp = (size_t)p * p;
+    double *A = nullptr, *B = nullptr;
+    int* d_status = nullptr;
+    int rc = [&]() -> int {
+        MG_TRY(dev_alloc(c, &d.T, np * p));
+        MG_TRY(dev_alloc(c, &d.lcol, pw)); MG_TRY(dev_alloc(c, &d.ucol, pw));
+        MG_TRY(dev_alloc(c, &d.lval, pw)); MG_TRY(dev_alloc(c, &d.uval, pw));
+        MG_TRY(dev_alloc(c, &d.y, np)); MG_TRY(dev_alloc(c, &d.x, np)); MG_TRY(dev_alloc(c, &d.w, (size_t)p));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&A), pp * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&B), pp * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_status), sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), c->stream));
+        const EllView e = ell_view(L);
+        const dim3 rows_grid(blocks_for(p, 128)), rows_blk(128);
+        const dim3 gj_grid(blocks_for(p, 256), (unsigned)p), gj_blk(256);
+        for (int k = 0; k < (int)nb; ++k) {
+            const size_t ko = (size_t)k * p * L.W;
+            HIP_TRY(hipMemsetAsync(A, 0, pp * 8, c->stream));
+            hipLaunchKernelGGL(bt_extract_dense, rows_grid, rows_blk, 0, c->stream, e, d.g, k, A, d_status);
+            hipLaunchKernelGGL(bt_extract_coupling, rows_grid, rows_blk, 0, c->stream, e, d.g, k, d.lcol + ko, d.lval + ko,
+                               d.ucol + ko, d.uval + ko);
+            if (k > 0) {
+                const size_t po = (size_t)(k - 1) * p * L.W;
+                hipLaunchKernelGGL(bt_schur_update, rows_grid, rows_blk, 0, c->stream, d.g, d.lcol + ko, d.lval + ko,
+                                   d.ucol + po, d.uval + po, d.T + (size_t)(k - 1) * pp, A);
+            }
+            double *in = A, *out = B;
+            for (int piv = 0; piv < (int)p; ++piv) {
+                hipLaunchKernelGGL(bt_gauss_jordan_step, gj_grid, gj_blk, 0, c->stream, (int)p, piv, in, out);
+                std::swap(in, out);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(d.T + (size_t)k * pp, in, pp * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        int status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        d.ok = status == 0;
+        return 0;
+    }();
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(d_status);
+    if (rc || !d.ok) { free_direct(c); d.tried = true; }
+    return rc;
+}
+
+int direct_solve(mg_context* c) {
+    DirectSolver& d = c->direct;
+    Level& L = c->L[0];
+    const int p = d.g.p, nb = d.g.nb;
+    const size_t pp = (size_t)p * p, pw = (size_t)p * d.g.W;
+    const int64_t first = std::min<int64_t>(L.nloc, p);
+    HIP_TRY(hipMemsetAsync(d.y, 0, (size_t)p * 8, c->stream));
+    HIP_TRY(hipMemcpyAsync(d.y, L.f.rows, (size_t)first * 8, hipMemcpyDeviceToDevice, c->stream));
+    const dim3 wave_grid(blocks_for(p, WAVES_PER_BLOCK)), blk(BLOCK);
+    for (int k = 1; k < nb; ++k)
+        hipLaunchKernelGGL(bt_forward, wave_grid, blk, 0, c->stream, d.g, k, d.lcol + k * pw, d.lval + k * pw,
+                           d.T + (size_t)(k - 1) * pp, L.f.rows, d.y);
+    for (int k = nb - 1; k >= 0; --k) {
+        hipLaunchKernelGGL(bt_backward_rhs, dim3(blocks_for(p, 128)), dim3(128), 0, c->stream, d.g, k, d.ucol + k * pw,
+                           d.uval + k * pw, d.y, d.x, d.w);
+        hipLaunchKernelGGL(bt_backward, wave_grid, blk, 0, c->stream, d.g, k, d.T + (size_t)k * pp, d.w, d.x, L.v.rows);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pcg_solve(mg_context* c, int* iters_out, double* rel_out);
+
+// Coarsest level: v = A^-1 f, standing in for the reference's exact spsolve (multigrid.py:239-241):
+// the block-tridiagonal LU where the level allows it, otherwise Jacobi-preconditioned CG.
 int coarse_solve(mg_context* c, int* iters_out, double* rel_out) {
+    if (!c->direct.tried) MG_TRY(build_direct(c));
+    if (c->direct.ok) {
+        if (iters_out) *iters_out = 0;
+        if (rel_out) *rel_out = 0.0;
+        return direct_solve(c);
+    }
+    return pcg_solve(c, iters_out, rel_out);
+}
+
+// Jacobi-preconditioned CG run to `coarse_rtol`.  Iterations are enqueued in batches; only the 4-byte
+// convergence flag crosses to the host between batches.
+int pcg_solve(mg_context* c, int* iters_out, double* rel_out) {
     Level& L = c->L[0];
     if (L.g.lead != 0) return fail("coarsest level must not be distributed");
     const int64_t n = L.nloc;
@@ -1044,6 +1168,9 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->nontemporal = value != 0;
     } else if (k == "overlap") {
         c->overlap = value != 0;
+    } else if (k == "coarse_direct") {
+        c->use_direct = value != 0;
+        free_direct(c);
     } else if (k == "pcg_chunk") {
         if (value < 1) return fail("pcg_chunk must be positive");
         c->pcg_chunk = (int)value;

@@ -78,7 +78,7 @@ class DeviceHierarchy:
     def __init__(self, dim: int, coarsest_level: int, finest_level: int, c: int = 8, device: int = 0,
                  rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
                  offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
-                 nontemporal: Optional[int] = None):
+                 nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -98,6 +98,8 @@ class DeviceHierarchy:
             self.set_tuning("strip_slices", strip_slices)
         if nontemporal is not None:
             self.set_tuning("nontemporal", nontemporal)
+        if coarse_direct is not None:
+            self.set_tuning("coarse_direct", coarse_direct)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):

@@ -240,9 +240,10 @@ def test_full_weighting_v_cycle_matches_oracle():
         assert rel_l2(dev.get_vector(3, "v"), want) <= TOL_ITER
 
 
-def test_residual_smooth_and_coarse_solve_match_oracle():
+@pytest.mark.parametrize("direct", [1, 0])
+def test_residual_smooth_and_coarse_solve_match_oracle(direct):
     from scipy.sparse.linalg import spsolve
-    bag, orc, dev = _oracle_and_device(2, 1, 2, 8, 3, 2)
+    bag, orc, dev = _oracle_and_device(2, 1, 2, 8, 3, 2, coarse_direct=direct)
     rng = np.random.default_rng(7)
     with dev:
         v = rng.standard_normal((bag.levels[2].n, 1))
@@ -256,7 +257,7 @@ def test_residual_smooth_and_coarse_solve_match_oracle():
         dev.set_vector(1, "f", bag.b_dict[1])
         its, rel = dev.coarse_solve()
         exact = spsolve(bag.A_sp_dict[1][0].tocsc(), bag.b_dict[1].ravel())
-        assert rel <= 1e-14 and its > 0
+        assert rel <= 1e-14 and (its == 0 if direct else its > 0)      # block LU does not iterate
         assert rel_l2(dev.get_vector(1, "v"), exact) <= 1e-12
         # zero right-hand side: the solver must return zero without iterating
         dev.set_vector(1, "f", np.zeros_like(bag.b_dict[1]))
@@ -492,3 +493,29 @@ def test_red_black_gauss_seidel_matches_oracle(dim, lo, hi, c, seed):
         dev.set_params(1, 1, 1.0, smoother="rbgs")
         with pytest.raises(MgError, match="two-colouring"):
             dev.smooth(hi, 1)
+
+
+@pytest.mark.parametrize("dim,N,seed", [(2, 16, None), (2, 32, 1), (2, 128, 2), (3, 8, 3), (3, 32, None)])
+def test_direct_coarsest_solve_is_exact(dim, N, seed):
+    """The block-tridiagonal LU that stands in for spsolve (multigrid.py:239-241): one block (N=16),
+    several blocks of several planes (2-D) and one plane per block (3-D, 33^3 = BASELINE's coarsest grid);
+    agrees with SuperLU and with the PCG fallback."""
+    from scipy.sparse.linalg import spsolve
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    lvl = poisson.make_level(N, dim, seed=seed)
+    rng = np.random.default_rng(8)
+    rhs = rng.standard_normal((lvl.n, 1))
+    exact = spsolve(lvl.A.tocsc(), rhs.ravel())
+    sols = []
+    for direct in (1, 0):
+        with DeviceHierarchy(dim, 0, 0, c=N, coarse_direct=direct) as dev:
+            dev.set_level(0, lvl.A, lvl.grid_index)
+            dev.set_params(1, 1, 2 / 3, coarse_rtol=1e-15)
+            dev.set_vector(0, "f", rhs)
+            its, _ = dev.coarse_solve()
+            assert (its == 0) == bool(direct)
+            sols.append(dev.get_vector(0, "v"))
+            dev.set_vector(0, "f", lvl.b)                      # second solve re-uses the factorisation
+            dev.coarse_solve()
+            assert np.abs(dev.get_vector(0, "v") - lvl.exact()).max() <= 1e-11
+    assert rel_l2(sols[0], exact) <= 1e-12 and rel_l2(sols[1], exact) <= 1e-11
