@@ -176,6 +176,7 @@ struct mg_context {
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
+    int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -230,7 +231,9 @@ void vec_free(mg_context* c, const Level& L, DVector* v) {
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
-dim3 grid3(const Grid& g, int nk) { return dim3((unsigned)((g.nx + 127) / 128), (unsigned)g.ny, (unsigned)nk); }
+// one thread per node of a plane (x), owned planes (y); block = kPlaneBlock threads
+constexpr int kPlaneBlock = 256;
+dim3 grid3(const Grid& g, int nk) { return dim3((unsigned)((g.plane + kPlaneBlock - 1) / kPlaneBlock), (unsigned)nk, 1u); }
 
 int check_level(mg_context* c, int level, bool must_be_set = true) {
     if (!c) return fail("null handle");
@@ -624,11 +627,26 @@ int restrict_to(mg_context* c, int level, int kind) {
     Grid gc = coarse_target_grid(c, C, F);
     if (kind == MG_RESTRICT_FULL_WEIGHTING) {
         MG_TRY(exchange_halo(c, F, F.v2));
-        hipLaunchKernelGGL(restrict_full_weighting, grid3(gc, gc.nk), dim3(128), 0, c->stream, gc, F.g, F.v2.base,
+        hipLaunchKernelGGL(restrict_full_weighting, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, gc, F.g, F.v2.base,
                            C.f.base);
     } else {
-        hipLaunchKernelGGL(restrict_inject, grid3(gc, gc.nk), dim3(128), 0, c->stream, gc, F.g, F.v2.base, C.f.base);
+        hipLaunchKernelGGL(restrict_inject, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, gc, F.g, F.v2.base, C.f.base);
     }
+    HIP_TRY(hipGetLastError());
+    if (C.replicated && !F.replicated) MG_TRY(allgather_planes(c, C.splits, C.g.plane, C.f.base));
+    return 0;
+}
+
+// r = f - A v evaluated at the coarse nodes only and injected (one launch instead of residual + restrict)
+int residual_restrict_fused(mg_context* c, int level) {
+    Level& F = c->L[level];
+    Level& C = c->L[level - 1];
+    const Grid gc = coarse_target_grid(c, C, F);
+    FusedRestrictArgs a{};
+    a.vals = F.vals; a.cols = F.cols; a.codes = F.codes; a.offsets = F.offsets;
+    a.x = F.v.base; a.f = F.f.rows; a.fc = C.f.base;
+    a.W = F.W; a.R = F.R; a.coded = F.coded ? 1 : 0; a.gc = gc; a.gf = F.g;
+    hipLaunchKernelGGL(residual_inject, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     if (C.replicated && !F.replicated) MG_TRY(allgather_planes(c, C.splits, C.g.plane, C.f.base));
     return 0;
@@ -641,11 +659,11 @@ int prolong(mg_context* c, int level, int add) {
     if (keep) MG_TRY(vec_alloc(c, F, &F.err));
     const dim3 grid = grid3(F.g, F.g.nk);
     if (add && keep)
-        hipLaunchKernelGGL((prolong_correct<true, true>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
+        hipLaunchKernelGGL((prolong_correct<true, true>), grid, dim3(kPlaneBlock), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
     else if (add)
-        hipLaunchKernelGGL((prolong_correct<true, false>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, (double*)nullptr);
+        hipLaunchKernelGGL((prolong_correct<true, false>), grid, dim3(kPlaneBlock), 0, c->stream, C.g, F.g, C.v.base, F.v.base, (double*)nullptr);
     else
-        hipLaunchKernelGGL((prolong_correct<false, true>), grid, dim3(128), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
+        hipLaunchKernelGGL((prolong_correct<false, true>), grid, dim3(kPlaneBlock), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
     HIP_TRY(hipGetLastError());
     if (add) MG_TRY(exchange_halo(c, F, F.v));
     return 0;
@@ -844,8 +862,12 @@ int vcycle(mg_context* c, int level) {
     if (level == 0) return coarse_solve(c, nullptr, nullptr);
     Level& C = c->L[level - 1];
     MG_TRY(smooth(c, level, c->mu1));
-    MG_TRY(residual(c, level));
-    MG_TRY(restrict_to(c, level, c->restriction));
+    if (c->restriction == MG_RESTRICT_INJECTION && c->fuse_restrict) {
+        MG_TRY(residual_restrict_fused(c, level));
+    } else {
+        MG_TRY(residual(c, level));
+        MG_TRY(restrict_to(c, level, c->restriction));
+    }
     MG_TRY(zero_vec(c, C, C.v));
     MG_TRY(vcycle(c, level - 1));
     MG_TRY(prolong(c, level, 1));
@@ -1168,6 +1190,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->nontemporal = value != 0;
     } else if (k == "overlap") {
         c->overlap = value != 0;
+    } else if (k == "fuse_restrict") {
+        c->fuse_restrict = value != 0;
     } else if (k == "coarse_direct") {
         c->use_direct = value != 0;
         free_direct(c);
@@ -1299,7 +1323,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     MG_TRY(alloc_level_vectors(c, L));
     unsigned long long* d_counts = reinterpret_cast<unsigned long long*>(c->partials);
     HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), c->stream));
-    const dim3 grid = grid3(L.g, L.g.nk), blk(128);
+    const dim3 grid = grid3(L.g, L.g.nk), blk(kPlaneBlock);
     switch (L.R) {
         case 1: hipLaunchKernelGGL(gen_poisson<1>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
         case 2: hipLaunchKernelGGL(gen_poisson<2>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;

@@ -49,6 +49,18 @@ struct Grid {
     int refine_y;            // 1 if the y axis takes part in coarsening (3-D)
 };
 
+// Transfer / generator kernels run one thread per node of a grid plane: blockIdx.x * blockDim.x +
+// threadIdx.x enumerates the plane (flattened, so odd line lengths leave no ragged tail per line),
+// blockIdx.y the owned planes.
+__device__ __forceinline__ bool plane_node(const Grid& g, int* i, int* j) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (unsigned)g.plane) return false;
+    const unsigned jj = t / (unsigned)g.nx;
+    *j = (int)jj;
+    *i = (int)(t - jj * (unsigned)g.nx);
+    return true;
+}
+
 // ---- XCD-aware block -> tile map ------------------------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 says which blocks share an L2).
 // With chunk c > 1, each XCD works on c consecutive tiles at a time, so lines of the
@@ -555,11 +567,11 @@ __device__ __forceinline__ bool gen_on_boundary(const GenArgs& a, int i, int j, 
 template <int R>
 __global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, double* f,
                             unsigned long long* counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int kl = blockIdx.z;              // local plane
+    int i = 0, j = 0;
+    const bool active = plane_node(a.g, &i, &j);
+    const int kl = blockIdx.y;              // local plane
     unsigned nz = 0, kept = 0;
-    if (i < a.g.nx) {
+    if (active) {
         const int k = a.g.k0 + kl;
         const int64_t lr = (int64_t)kl * a.g.plane + (int64_t)j * a.g.nx + i;
         const int64_t slice = lr / (WAVE * R);
@@ -606,24 +618,70 @@ __global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, do
 // ---- grid transfers (lexicographic index arithmetic; no coordinate hashing) ---------------------
 // Injection (Restriction2D_direct, multigrid.py:123-132): coarse (I,J,K) <- fine (2I,2J,2K).
 __global__ void restrict_inject(Grid gc, Grid gf, const double* __restrict__ rf, double* __restrict__ fc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int kl = blockIdx.z;
-    if (i >= gc.nx) return;
+    int i, j;
+    if (!plane_node(gc, &i, &j)) return;
+    const int kl = blockIdx.y;
     const int kf = 2 * (gc.k0 + kl) - gf.k0;                 // local fine plane
     const int jf = gf.refine_y ? 2 * j : j;
     const int64_t src = gf.lead + (int64_t)kf * gf.plane + (int64_t)jf * gf.nx + 2 * i;
     fc[gc.lead + (int64_t)kl * gc.plane + (int64_t)j * gc.nx + i] = rf[src];
 }
 
+// Residual + injection in one pass (multigrid.py:244 followed by :251-252): with injection only the
+// residual at the coarse nodes survives, so only those rows (every other row of every other line of
+// every other plane) are evaluated -- a quarter of the matrix bytes of a full residual sweep.  Same
+// per-row arithmetic as ell_apply<..., MODE_RESIDUAL>, hence bit-identical coarse right-hand sides.
+struct FusedRestrictArgs {
+    const double* vals; const int* cols; const unsigned long long* codes; const int* offsets;
+    const double* x;        // fine iterate, base of storage
+    const double* f;        // fine right-hand side, row-based
+    double* fc;             // coarse right-hand side, base of storage
+    int W, R, coded;
+    Grid gc, gf;
+};
+
+__global__ void residual_inject(FusedRestrictArgs a) {
+    __shared__ int s_off[256];
+    if (a.coded) {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) s_off[t] = a.offsets[t];
+        __syncthreads();
+    }
+    int i, j;
+    if (!plane_node(a.gc, &i, &j)) return;
+    const int kl = blockIdx.y;
+    const int kf = 2 * (a.gc.k0 + kl) - a.gf.k0;
+    const int jf = a.gf.refine_y ? 2 * j : j;
+    const int64_t row = (int64_t)kf * a.gf.plane + (int64_t)jf * a.gf.nx + 2 * i;       // local fine row
+    const int64_t S = (int64_t)WAVE * a.R;
+    const int64_t slice = row / S, within = row % S;
+    const size_t base = (size_t)slice * a.W * S + within;
+    double acc = 0.0;
+    if (a.coded) {
+        const int CW = (a.W + 7) / 8;
+        const size_t cbase = (size_t)slice * CW * S + within;
+        const double* xrow = a.x + a.gf.lead + row;
+        for (int q = 0; q < CW; ++q) {
+            const unsigned long long w = a.codes[cbase + (size_t)q * S];
+            const int kend = min(8, a.W - 8 * q);
+            for (int kk = 0; kk < kend; ++kk) {
+                const int code = (int)((w >> (8 * kk)) & 0xffull);
+                acc = fma(a.vals[base + (size_t)(8 * q + kk) * S], xrow[s_off[code]], acc);
+            }
+        }
+    } else {
+        for (int k = 0; k < a.W; ++k)
+            acc = fma(a.vals[base + (size_t)k * S], a.x[a.cols[base + (size_t)k * S]], acc);
+    }
+    a.fc[a.gc.lead + (int64_t)kl * a.gc.plane + (int64_t)j * a.gc.nx + i] = a.f[row] - acc;
+}
+
 // Full weighting (Restriction2D, multigrid.py:135-198); neighbours outside the grid are skipped
 // (:172-194).  2-D: (1/16)(corners + 2 edges + 4 centre) in the reference's summation order;
 // 3-D (no reference): (1/64)(corners + 2 edges + 4 faces + 8 centre).  Needs valid fine halos.
 __global__ void restrict_full_weighting(Grid gc, Grid gf, const double* __restrict__ rf, double* __restrict__ fc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int kl = blockIdx.z;
-    if (i >= gc.nx) return;
+    int i, j;
+    if (!plane_node(gc, &i, &j)) return;
+    const int kl = blockIdx.y;
     const int K = gc.k0 + kl;
     const int fi = 2 * i, fk = 2 * K;
     auto at = [&](int di, int dj, int dk, double& acc) {
@@ -659,10 +717,9 @@ __global__ void restrict_full_weighting(Grid gc, Grid gf, const double* __restri
 template <bool ADD, bool KEEP>
 __global__ void prolong_correct(Grid gc, Grid gf, const double* __restrict__ vc, double* __restrict__ vf,
                                 double* __restrict__ err) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int kl = blockIdx.z;
-    if (i >= gf.nx) return;
+    int i, j;
+    if (!plane_node(gf, &i, &j)) return;
+    const int kl = blockIdx.y;
     const int k = gf.k0 + kl;
     const int pi = i & 1, pk = k & 1;
     const int pj = gf.refine_y ? (j & 1) : 0;

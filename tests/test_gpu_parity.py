@@ -519,3 +519,22 @@ def test_direct_coarsest_solve_is_exact(dim, N, seed):
             dev.coarse_solve()
             assert np.abs(dev.get_vector(0, "v") - lvl.exact()).max() <= 1e-11
     assert rel_l2(sols[0], exact) <= 1e-12 and rel_l2(sols[1], exact) <= 1e-11
+
+
+@pytest.mark.parametrize("dim,lo,hi,c", [(2, 1, 3, 8), (3, 1, 3, 4)])
+def test_fused_residual_injection_is_bit_identical(dim, lo, hi, c):
+    """vcycle() evaluates the residual at the coarse nodes only when restricting by injection; the coarse
+    right-hand side and the iterate must equal the two-kernel path bit for bit (int32 and coded columns)."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=3, mu2=3, seed=12)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    f = bag.b_dict[hi]
+    for codes in (1, 0):
+        outs = []
+        for fused in (1, 0):
+            with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, offset_codes=codes) as dev:
+                dev.set_tuning("fuse_restrict", fused)
+                v = _one_cycle(dev, hi, f)
+                outs.append((v, dev.get_vector(hi - 1, "f"), dev.get_vector(hi - 1, "v")))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
