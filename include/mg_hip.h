@@ -173,6 +173,11 @@ int mg_copy_vector(mg_handle h, int level, int dst_which, int src_which);
  *              multigrid.py:279).  elements_per_dim == 0 in mg_set_level_csr declares a
  *              "flat" level (any square matrix, smoother/residual only, single GPU). */
 int mg_smooth(mg_handle h, int level, int nw);
+/* jacobiRelaxation on the reference's own split operands (multigrid.py:223-228), for callers that hand
+ * over (D^-1 R, D^-1) rather than A: the level's matrix is D^-1 (A - D) (set with
+ * mg_set_tuning("require_diagonal", 0)), MG_VEC_ERR holds the diagonal of D^-1, and every sweep is
+ * (1-w) v + w (D^-1 f) - w (D^-1 R) v evaluated in the reference's order. */
+int mg_smooth_split(mg_handle h, int level, int nw);
 int mg_residual(mg_handle h, int level);
 int mg_restrict(mg_handle h, int level, int kind);
 int mg_prolong(mg_handle h, int level, int add);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mg_zero_vector": [_H, C.c_int, C.c_int],
     "mg_copy_vector": [_H, C.c_int, C.c_int, C.c_int],
     "mg_smooth": [_H, C.c_int, C.c_int],
+    "mg_smooth_split": [_H, C.c_int, C.c_int],
     "mg_residual": [_H, C.c_int],
     "mg_restrict": [_H, C.c_int, C.c_int],
     "mg_prolong": [_H, C.c_int, C.c_int],

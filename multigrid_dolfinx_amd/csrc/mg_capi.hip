@@ -176,6 +176,7 @@ struct mg_context {
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
+    int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
@@ -1190,6 +1191,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->nontemporal = value != 0;
     } else if (k == "overlap") {
         c->overlap = value != 0;
+    } else if (k == "require_diagonal") {
+        c->require_diagonal = value != 0;
     } else if (k == "fuse_restrict") {
         c->fuse_restrict = value != 0;
     } else if (k == "coarse_direct") {
@@ -1248,7 +1251,7 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
     HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (stats[2] & 1ull) { cleanup(); return fail("a matrix row couples unknowns more than one grid plane apart (not a slab-local stencil)"); }
-    if (stats[2] & 2ull) { cleanup(); return fail("a matrix row has a zero or missing diagonal"); }
+    if ((stats[2] & 2ull) && c->require_diagonal) { cleanup(); return fail("a matrix row has a zero or missing diagonal"); }
     L.W = (int)std::max<unsigned long long>(1, stats[0]);
     L.nnz_stored = stats[1];
     if (int r = alloc_ell(c, L)) { cleanup(); return r; }
@@ -1486,6 +1489,24 @@ int mg_smooth(mg_handle c, int level, int nw) {
     HIP_TRY(hipSetDevice(c->device));
     MG_TRY(exchange_halo(c, c->L[level], c->L[level].v));
     return smooth(c, level, nw);
+}
+
+int mg_smooth_split(mg_handle c, int level, int nw) {
+    MG_TRY(need_matrix(c, level));
+    if (nw < 0) return fail("nw must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    if (!L.replicated && c->comm.active()) return fail("mg_smooth_split is single-GPU only");
+    if (!L.err.raw) return fail("MG_VEC_ERR must hold the diagonal of D^-1");
+    const unsigned nb = (unsigned)std::min<int64_t>(2048, (L.nloc + 255) / 256);
+    for (int s = 0; s < nw; ++s) {
+        MG_TRY(launch_ell(c, L, MODE_SPMV, false, L.v.base, nullptr, L.v2.rows, nullptr, nullptr));
+        hipLaunchKernelGGL(jacobi_split_combine, dim3(nb), dim3(256), 0, c->stream, L.v.rows, L.f.rows, L.err.rows,
+                           L.v2.rows, L.v2.rows, L.nloc, c->omega);
+        std::swap(L.v, L.v2);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int mg_residual(mg_handle c, int level) {

@@ -768,6 +768,16 @@ __global__ void gather_out(const double* __restrict__ x, const int* __restrict__
     }
 }
 
+// jacobiRelaxation in the reference's own split form (multigrid.py:226):
+//     out = (1 - w) v + w (D^-1 f) - w q        with q = (D^-1 R) v from ell_apply<..., MODE_SPMV>,
+// evaluated left to right like the NumPy expression.  q and out may alias.
+__global__ void jacobi_split_combine(const double* __restrict__ v, const double* __restrict__ f,
+                                     const double* __restrict__ dinv, const double* q, double* out, int64_t n,
+                                     double omega) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = ((1.0 - omega) * v[t] + omega * (dinv[t] * f[t])) - omega * q[t];
+}
+
 // partial sums of x.y over n entries -> partials[blockIdx]; deterministic (no atomics)
 __global__ __launch_bounds__(BLOCK) void dot_partial(const double* __restrict__ x, const double* __restrict__ y,
                                                       int64_t n, double* __restrict__ partials) {

@@ -290,6 +290,10 @@ class DeviceHierarchy:
     def smooth(self, level: int, nw: int):
         check(self._lib.mg_smooth(self._h, self._idx(level), int(nw)))
 
+    def smooth_split(self, level: int, nw: int):
+        """Sweeps in the reference's split-operand form (matrix = D^-1 R, "err" = diagonal of D^-1)."""
+        check(self._lib.mg_smooth_split(self._h, self._idx(level), int(nw)))
+
     def residual(self, level: int):
         check(self._lib.mg_residual(self._h, self._idx(level)))
 

@@ -236,15 +236,16 @@ def err_calculator(u, u_exact, V_space):
 # ---- the hot path --------------------------------------------------------------------------------------------------------
 def _smoother_context(A):
     """Stand-alone smoother on `(D^-1 R, D^-1, level)` operands that do not belong to the initialised
-    problem: rebuild A = D + D (D^-1 R) once and keep it on the device."""
+    problem: the two operands go to the device as they are and the sweeps run in the reference's split
+    form (`mg_smooth_split`)."""
     key = ("jac", id(A[0]))
     hit = _adhoc.get(key)
     if hit is not None and hit[1] is A[0]:
         return hit[0]
-    d = 1.0 / A[1].diagonal()
-    full = (sp.diags(d, 0) @ A[0] + sp.diags(d, 0)).tocsr()
     h = DeviceHierarchy(_options["dim"], 0, 0, c=1, device=_options["device"])
-    h.set_flat_level(full)
+    h.set_tuning("require_diagonal", 0)
+    h.set_flat_level(A[0].tocsr() if not sp.isspmatrix_csr(A[0]) else A[0])
+    h.set_vector(0, "err", A[1].diagonal())
     if len(_adhoc) >= 8:
         _release(_adhoc.pop(next(iter(_adhoc)))[0])
     _adhoc[key] = (h, A[0], None)
@@ -263,7 +264,10 @@ def jacobiRelaxation(A, v, f, nw):
         h.set_params(0, 0, omega if omega is not None else 2.0 / 3.0)
     h.set_vector(level, "v", v)
     h.set_vector(level, "f", f)
-    h.smooth(level, nw)
+    if registered:
+        h.smooth(level, nw)
+    else:
+        h.smooth_split(level, nw)
     return h.get_vector(level, "v")
 
 
