@@ -143,7 +143,8 @@ int mg_set_tuning(mg_handle h, const char* key, int64_t value);
 /* ---- level queries ------------------------------------------------------------------- */
 int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, int64_t* row0,
                   int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated,
-                  int* offset_codes /* 0 = int32 columns, else number of distinct offsets */);
+                  int* offset_codes /* 0 = int32 columns; > 0 = offset codes (number of distinct
+                                       offsets); < 0 = symmetric diagonal storage (-stored diagonals) */);
 
 /* ---- vectors ---------------------------------------------------------------------------
  * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the

@@ -126,6 +126,12 @@ struct Level {
     int ntable = 0, dcode = 0;
     bool coded = false;
     bool rb_ok = false;                     // index parity is a valid red-black colouring of the matrix
+    // symmetric diagonal storage (replaces vals + codes when the matrix is bit-for-bit symmetric)
+    double* dvals = nullptr;
+    bool sdia = false;
+    int wu = 0;
+    int up[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t mlead = 0, mslices = 0;
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
     int* perm = nullptr;
@@ -161,6 +167,7 @@ struct mg_context {
     int keep_err = 0;
     // tuning
     int use_codes = 1;          // offset-coded columns where a level allows it
+    int use_sdia = 1;           // symmetric diagonal storage where a level is bit-for-bit symmetric
     int strip_slices = 0;       // XCD strip traversal for 3-D levels (0 = chunked map only; measured: no gain)
     int nontemporal = 1;        // streaming loads for matrix / rhs data
     int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
@@ -210,22 +217,31 @@ void dev_free(mg_context* c, T*& p, size_t count) {
 
 // Elements past the end of every vector: rows of the last, partly filled slice read (and ignore)
 // x[row] for up to 64*R - 1 rows beyond nloc in the offset-coded kernels.
+// The symmetric-diagonal kernels apply every offset to every row (absent entries are stored zeros), so
+// the first / last rows also read x up to the largest offset before / after the vector.  Grid levels
+// get zero-filled slack for the widest P1 pattern (offset plane + nx + 1) on both sides; a level whose
+// offsets reach further keeps the coded format (repack_sdia checks against vec_reach).
 constexpr int64_t kVecSlack = 260;
+
+inline int64_t vec_reach(const Level& L) { return L.flat ? 0 : L.g.plane + L.g.nx + 4; }
+inline int64_t vec_front(const Level& L) {
+    const int64_t slack = ((vec_reach(L) + 3) / 4) * 4;
+    return slack + (4 - (L.g.lead % 4)) % 4;
+}
+inline int64_t vec_total(const Level& L) { return vec_front(L) + L.xlen + kVecSlack + vec_reach(L); }
 
 int vec_alloc(mg_context* c, const Level& L, DVector* v) {
     if (v->raw) return 0;
-    const int64_t pad = (4 - (L.g.lead % 4)) % 4;
-    MG_TRY(dev_alloc(c, &v->raw, (size_t)(L.xlen + pad + kVecSlack)));
-    v->base = v->raw + pad;
+    MG_TRY(dev_alloc(c, &v->raw, (size_t)vec_total(L)));
+    v->base = v->raw + vec_front(L);
     v->rows = v->base + L.g.lead;
-    HIP_TRY(hipMemsetAsync(v->raw, 0, (size_t)(L.xlen + pad + kVecSlack) * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(v->raw, 0, (size_t)vec_total(L) * sizeof(double), c->stream));
     return 0;
 }
 
 void vec_free(mg_context* c, const Level& L, DVector* v) {
     if (v->raw) {
-        const int64_t pad = (4 - (L.g.lead % 4)) % 4;
-        dev_free(c, v->raw, (size_t)(L.xlen + pad + kVecSlack));
+        dev_free(c, v->raw, (size_t)vec_total(L));
         v->base = v->rows = nullptr;
     }
 }
@@ -328,8 +344,10 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.cols, ell);
     dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * (WAVE * L.R));
     dev_free(c, L.offsets, 256);
+    dev_free(c, L.dvals, (size_t)L.mslices * (L.wu > 0 ? L.wu : 1) * (WAVE * L.R));
     L.coded = false;
     L.rb_ok = false;
+    L.sdia = false;
     dev_free(c, L.dinv, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.perm, (size_t)L.n_global);
     vec_free(c, L, &L.v);
@@ -376,6 +394,29 @@ void launch_ell_coded_wr(int mode, bool dot, bool nt, const EllArgs& a, unsigned
     else launch_ell_coded_wrn<WT, R, false>(mode, dot, a, grid, s);
 }
 
+template <int WU, int R, bool NT>
+void launch_sdia_wrn(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (mode == MODE_RESIDUAL)
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_JACOBI)
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_GS)
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (dot)
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
+template <int R>
+void launch_sdia_r(int WU, int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s) {
+    switch (WU) {
+        case 3: nt ? launch_sdia_wrn<3, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<3, R, false>(mode, dot, a, grid, s); break;
+        case 4: nt ? launch_sdia_wrn<4, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<4, R, false>(mode, dot, a, grid, s); break;
+        default: nt ? launch_sdia_wrn<8, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<8, R, false>(mode, dot, a, grid, s); break;
+    }
+}
+
 // widths with an offset-coded specialisation
 inline bool coded_width(int W) { return W == 5 || W == 7 || W == 15; }
 
@@ -412,6 +453,20 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
     a.color = color; a.parity0 = (int)(L.row0 & 1);
     unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
+    if (L.sdia) {
+        a.vals = L.dvals; a.mlead = L.mlead;
+        for (int t = 0; t < 8; ++t) a.up[t] = L.up[t];
+        if (grid_out) *grid_out = grid;
+        const bool nt = c->nontemporal != 0;
+        switch (L.R) {
+            case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, a, grid, c->stream); break;
+            case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, a, grid, c->stream); break;
+            case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, a, grid, c->stream); break;
+            default: return fail("unsupported rows_per_lane");
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (L.coded) {
         // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
         const int64_t ps4 = (L.g.plane / (WAVE * L.R)) / 4;            // blocks per pseudo-plane
@@ -647,6 +702,10 @@ int residual_restrict_fused(mg_context* c, int level) {
     a.vals = F.vals; a.cols = F.cols; a.codes = F.codes; a.offsets = F.offsets;
     a.x = F.v.base; a.f = F.f.rows; a.fc = C.f.base;
     a.W = F.W; a.R = F.R; a.coded = F.coded ? 1 : 0; a.gc = gc; a.gf = F.g;
+    if (F.sdia) {
+        a.vals = F.dvals; a.W = F.wu; a.coded = 2; a.mlead = F.mlead;
+        for (int t = 0; t < 8; ++t) a.up[t] = F.up[t];
+    }
     hipLaunchKernelGGL(residual_inject, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     if (C.replicated && !F.replicated) MG_TRY(allgather_planes(c, C.splits, C.g.plane, C.f.base));
@@ -957,6 +1016,63 @@ int encode_level(mg_context* c, Level& L) {
     return 0;
 }
 
+// Symmetric diagonal storage: possible when the level is offset-coded, its offsets come in +/- pairs
+// and every lower entry equals its transposed partner bit for bit (mg_kernels.hip.h, sdia_*).
+// The coarsest level keeps the coded form (the direct solver reads it).
+int repack_sdia(mg_context* c, Level& L, int level) {
+    if (!c->use_sdia || !L.coded || level == 0 || L.flat) return 0;
+    std::vector<int> offs(256);
+    HIP_TRY(hipMemcpy(offs.data(), L.offsets, 256 * sizeof(int), hipMemcpyDeviceToHost));
+    offs.resize(L.ntable);
+    std::vector<int> up{0};
+    for (int o : offs) {
+        if (o > 0) up.push_back(o);
+        if (o != 0 && std::find(offs.begin(), offs.end(), -o) == offs.end()) return 0;     // not a symmetric pattern
+    }
+    const int wu = (int)up.size();
+    if (2 * wu - 1 != L.ntable || wu > 8) return 0;
+    if (up.back() > vec_reach(L)) return 0;                     // x slack would not cover the reach
+    const int wu_t = wu <= 3 ? 3 : (wu <= 4 ? 4 : 8);          // template width actually launched
+    const int64_t S = (int64_t)WAVE * L.R;
+    const int64_t mlead = ((up.back() + S - 1) / S) * S;
+    const int64_t mslices = (L.nloc + mlead + S - 1) / S;
+    SdiaArgs a{};
+    a.vals = L.vals; a.codes = L.codes; a.offsets = L.offsets; a.W = L.W; a.WU = wu_t; a.NU = wu; a.dcode = L.dcode;
+    for (int t = 0; t < 8; ++t) a.up[t] = t < wu ? up[t] : 0;
+    a.nloc = L.nloc; a.mlead = mlead;
+    double* dvals = nullptr;
+    MG_TRY(dev_alloc(c, &dvals, (size_t)mslices * wu_t * S));
+    a.dvals = dvals;
+    int* d_flag = nullptr;
+    int flag = 0;
+    int rc = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flag), sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(dvals, 0, (size_t)mslices * wu_t * S * sizeof(double), c->stream));
+        const dim3 grid(blocks_for(L.nloc, 256)), blk(256);
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(sdia_fill<1>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<1>, grid, blk, 0, c->stream, a, d_flag); break;
+            case 2: hipLaunchKernelGGL(sdia_fill<2>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<2>, grid, blk, 0, c->stream, a, d_flag); break;
+            default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<4>, grid, blk, 0, c->stream, a, d_flag); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    (void)hipFree(d_flag);
+    if (rc || flag) {                                           // not symmetric: keep the coded form
+        dev_free(c, dvals, (size_t)mslices * wu_t * S);
+        return rc;
+    }
+    L.dvals = dvals; L.sdia = true; L.wu = wu_t; L.mlead = mlead; L.mslices = mslices;
+    for (int t = 0; t < 8; ++t) L.up[t] = t < wu ? up[t] : 0;
+    // padded template slots (wu < wu_t) hold zeros and offset 0: they add 0 * x[row]
+    dev_free(c, L.vals, (size_t)L.nslices * L.W * S);
+    dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * S);
+    return 0;
+}
+
 int finish_level(mg_context* c, Level& L) {
     MG_TRY(alloc_level_vectors(c, L));
     L.set = true;
@@ -1184,6 +1300,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         for (auto& L : c->L)
             if (L.set) return fail("offset_codes must be chosen before level set-up");
         c->use_codes = value != 0;
+    } else if (k == "symmetric_storage") {
+        for (auto& L : c->L)
+            if (L.set) return fail("symmetric_storage must be chosen before level set-up");
+        c->use_sdia = value != 0;
     } else if (k == "strip_slices") {
         if (value < 0 || value > 4096 || value % 4) return fail("strip_slices must be a multiple of 4 in 0..4096");
         c->strip_slices = (int)value;
@@ -1278,6 +1398,7 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
     HIP_TRY(hipStreamSynchronize(c->stream));
     cleanup();
     MG_TRY(encode_level(c, L));
+    MG_TRY(repack_sdia(c, L, level));
     L.has_matrix = true;
     return finish_level(c, L);
 }
@@ -1339,6 +1460,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     L.nnz_stored = counts[0];
     L.nnz_nonzero = counts[1];
     MG_TRY(encode_level(c, L));
+    MG_TRY(repack_sdia(c, L, level));
     // the generated right-hand side is also this level's true right-hand side for mg_fmg
     if (level + 1 < c->nlev) {
         MG_TRY(vec_alloc(c, L, &L.ftrue));
@@ -1400,7 +1522,7 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
     if (nnz_nonzero) *nnz_nonzero = (int64_t)L.nnz_nonzero;
     if (ell_width) *ell_width = L.W;
     if (replicated) *replicated = L.replicated ? 1 : 0;
-    if (offset_codes) *offset_codes = L.coded ? L.ntable : 0;
+    if (offset_codes) *offset_codes = L.sdia ? -L.wu : (L.coded ? L.ntable : 0);
     return 0;
 }
 

@@ -122,6 +122,9 @@ struct EllArgs {
     // XCD strip traversal (strip_ns == 0: chunked map): see strip_block()
     int color;              // MODE_GS: colour relaxed by this launch
     int parity0;            // MODE_GS: parity of the global index of local row 0
+    // symmetric-diagonal storage (sdia_apply): up[0] = 0, up[1..] = the positive offsets, ascending
+    int up[8];
+    int64_t mlead;          // matrix rows stored in front of row 0 (multiple of the slice height)
     unsigned strip_ns;      // strips per pseudo-plane, a multiple of 8 (one share per XCD)
     unsigned strip_bmax;    // blocks (4 slices each) in the widest strip
     unsigned ps4;           // blocks per pseudo-plane
@@ -180,6 +183,53 @@ template <int R, bool NT> __device__ __forceinline__ void store_d(double* p, con
     else { dvec4_t t; t.x = v.d[0]; t.y = v.d[1]; t.z = v.d[2 % R]; t.w = v.d[3 % R]; __builtin_nontemporal_store(t, reinterpret_cast<dvec4_t*>(p)); }
 }
 
+// Shared output stage of the offset-coded and symmetric-diagonal kernels: acc = (A x)_row, diag = a_ii,
+// xr = x_row for the R rows of this lane.
+template <int R, int MODE, bool DOT, bool NT>
+__device__ __forceinline__ void tile_epilogue(const EllArgs& a, int64_t row, const double* acc, const double* diag,
+                                              const double* xr, double& dot) {
+    DVec<R> o;
+        if (MODE != MODE_GS && row + R <= a.nloc) {
+            if (MODE == MODE_SPMV) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) o.d[r] = acc[r];
+                if (DOT) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dot += xr[r] * acc[r];
+                }
+            } else {
+                const DVec<R> fr = load_d<R, NT>(a.f + row);
+                if (MODE == MODE_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) o.d[r] = fr.d[r] - acc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) o.d[r] = xr[r] + (a.omega * (1.0 / diag[r])) * (fr.d[r] - acc[r]);
+                }
+            }
+            // the Jacobi / SpMV output is the next sweep's gathered source: keep it cacheable
+            store_d<R, NT && MODE == MODE_RESIDUAL>(a.out + row, o);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t rr = row + r;
+                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
+                if (rr < a.nloc) {
+                    double val;
+                    if (MODE == MODE_SPMV) {
+                        val = acc[r];
+                        if (DOT) dot += xr[r] * acc[r];
+                    } else if (MODE == MODE_RESIDUAL) {
+                        val = a.f[rr] - acc[r];
+                    } else {
+                        val = xr[r] + (a.omega * (1.0 / diag[r])) * (a.f[rr] - acc[r]);
+                    }
+                    a.out[rr] = val;
+                }
+            }
+        }
+    }
+
 // Offset-coded variant of ell_apply (same modes, same arithmetic, 8 B of column data per row).
 template <int WT, int R, int MODE, bool DOT, bool NT>
 __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
@@ -229,51 +279,143 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
                 acc[r] = fma(val, xv, acc[r]);
             }
         }
-        DVec<R> o;
-        if (MODE != MODE_GS && row + R <= a.nloc) {
-            if (MODE == MODE_SPMV) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) o.d[r] = acc[r];
-                if (DOT) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) dot += xr[r] * acc[r];
-                }
-            } else {
-                const DVec<R> fr = load_d<R, NT>(a.f + row);
-                if (MODE == MODE_RESIDUAL) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) o.d[r] = fr.d[r] - acc[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) o.d[r] = xr[r] + (a.omega * (1.0 / diag[r])) * (fr.d[r] - acc[r]);
-                }
-            }
-            // the Jacobi / SpMV output is the next sweep's gathered source: keep it cacheable
-            store_d<R, NT && MODE == MODE_RESIDUAL>(a.out + row, o);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t rr = row + r;
-                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
-                if (rr < a.nloc) {
-                    double val;
-                    if (MODE == MODE_SPMV) {
-                        val = acc[r];
-                        if (DOT) dot += xr[r] * acc[r];
-                    } else if (MODE == MODE_RESIDUAL) {
-                        val = a.f[rr] - acc[r];
-                    } else {
-                        val = xr[r] + (a.omega * (1.0 / diag[r])) * (a.f[rr] - acc[r]);
-                    }
-                    a.out[rr] = val;
-                }
-            }
-        }
+        tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
     }
     if (DOT) {
         const double t = block_sum(dot);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
     }
+}
+
+// ---- symmetric diagonal storage ---------------------------------------------------------------
+// When a level's offsets are symmetric (o in the table <=> -o in the table, which every grid stencil
+// satisfies) and the matrix is bit-for-bit symmetric (a_ij == a_ji: checked at set-up), entry k of every
+// row can sit in the slot of its offset, which makes the per-row codes redundant, and the lower entry at
+// offset -d of row i is the upper entry at +d of row i-d, which makes the lower half redundant:
+//     dvals[(((row + mlead) / S) * WU + c) * S + (row + mlead) % S]    c = 0 diagonal, c >= 1 offset +up[c]
+// with S = 64*R and WU = (W+1)/2 (4 for 7-point rows).  The kernel streams 8*WU bytes per row (32 B
+// instead of 56 + 8), re-reads the lower entries as shifted, coalesced loads that hit L2 / Infinity
+// Cache like the x neighbours do, and applies them in ascending column order -- the same fma chain as the
+// other kernels, so results are bit-identical.  `mlead` rows in front of row 0 hold the lower entries
+// of the first rows whose partner rows live on another slab (or do not exist: zeros).
+// Per row and sweep: 32 (matrix) + 8 (x) + 8 (f) + 8 (out) = 56 B.
+template <int WU, int R, int MODE, bool DOT, bool NT>
+__global__ __launch_bounds__(BLOCK) void sdia_apply(EllArgs a) {
+    if (a.done_flag && *a.done_flag) return;
+    constexpr int S = WAVE * R;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    double dot = 0.0;
+    if (sl < a.nslices) {
+        const int64_t slice = a.slice0 + sl;
+        const int64_t row = slice * S + (int64_t)lane * R;
+        const int64_t m = row + a.mlead;                               // matrix row of r = 0 (m % S == lane*R)
+        const size_t base = (size_t)(m / S) * WU * S + (size_t)lane * R;
+        const double* xrow = a.x + a.lead + row;
+        DVec<R> up[WU];
+        // the diagonal is read once (streamed); the upper slots are read again as the lower entries of
+        // later rows and must stay cacheable
+        up[0] = load_d<R, NT>(a.vals + base);
+#pragma unroll
+        for (int c = 1; c < WU; ++c) up[c] = load_d<R, false>(a.vals + base + (size_t)c * S);
+        double lo[WU][R];
+#pragma unroll
+        for (int c = 1; c < WU; ++c) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t mm = m + r - a.up[c];
+                lo[c][r] = a.vals[((size_t)(mm / S) * WU + c) * S + (size_t)(mm % S)];
+            }
+        }
+        double acc[R], diag[R], xr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = 0.0;
+#pragma unroll
+            for (int c = WU - 1; c >= 1; --c) acc[r] = fma(lo[c][r], xrow[r - a.up[c]], acc[r]);
+            xr[r] = xrow[r];
+            diag[r] = up[0].d[r] != 0.0 ? up[0].d[r] : 1.0;
+            acc[r] = fma(up[0].d[r], xr[r], acc[r]);
+#pragma unroll
+            for (int c = 1; c < WU; ++c) acc[r] = fma(up[c].d[r], xrow[r + a.up[c]], acc[r]);
+        }
+        tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
+    }
+    if (DOT) {
+        const double t = block_sum(dot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+    }
+}
+
+struct SdiaArgs {
+    const double* vals;                 // offset-coded ELL being converted
+    const unsigned long long* codes;
+    const int* offsets;                 // code -> offset
+    int W, WU, NU, dcode;               // WU = slots laid out, NU <= WU = slots in use
+    int up[8];                          // slot -> positive offset (up[0] = 0; unused slots 0)
+    int64_t nloc, mlead;
+    double* dvals;
+};
+
+__device__ __forceinline__ int sdia_slot(const SdiaArgs& a, int off) {
+    for (int c = 0; c < a.NU; ++c)
+        if (a.up[c] == off) return c;
+    return 0;
+}
+
+// Pass 1: diagonal and upper entries of every row; lower entries whose partner row is not stored
+// locally go to the partner's slot in the lead region.
+template <int R>
+__global__ void sdia_fill(SdiaArgs a) {
+    constexpr int S = WAVE * R;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    const int CW = (a.W + 7) / 8;
+    const int64_t slice = row / S, within = row % S;
+    const int64_t m = row + a.mlead;
+    for (int k = 0; k < a.W; ++k) {
+        const double v = a.vals[((size_t)slice * a.W + k) * S + within];
+        if (v == 0.0) continue;
+        const unsigned long long w = a.codes[((size_t)slice * CW + k / 8) * S + within];
+        const int off = a.offsets[(int)((w >> (8 * (k % 8))) & 0xffull)];
+        if (off >= 0) {
+            const int c = sdia_slot(a, off);
+            a.dvals[((size_t)(m / S) * a.WU + c) * S + (size_t)(m % S)] = v;
+        } else if (row + off < 0) {
+            const int c = sdia_slot(a, -off);
+            const int64_t mm = m + off;
+            a.dvals[((size_t)(mm / S) * a.WU + c) * S + (size_t)(mm % S)] = v;
+        }
+    }
+}
+
+// Pass 2: every row's lower entries (absent = 0) must equal, bit for bit, what the symmetric kernel will
+// read for them; flag[0] |= 1 otherwise.
+template <int R>
+__global__ void sdia_check(SdiaArgs a, int* flag) {
+    constexpr int S = WAVE * R;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    const int CW = (a.W + 7) / 8;
+    const int64_t slice = row / S, within = row % S;
+    const int64_t m = row + a.mlead;
+    double lower[8];
+    for (int c = 0; c < 8; ++c) lower[c] = 0.0;
+    for (int k = 0; k < a.W; ++k) {
+        const double v = a.vals[((size_t)slice * a.W + k) * S + within];
+        if (v == 0.0) continue;
+        const unsigned long long w = a.codes[((size_t)slice * CW + k / 8) * S + within];
+        const int off = a.offsets[(int)((w >> (8 * (k % 8))) & 0xffull)];
+        if (off < 0) lower[sdia_slot(a, -off)] = v;
+    }
+    bool bad = false;
+    for (int c = 1; c < a.NU; ++c) {
+        const int64_t mm = m - a.up[c];
+        const double want = a.dvals[((size_t)(mm / S) * a.WU + c) * S + (size_t)(mm % S)];
+        if (__double_as_longlong(want) != __double_as_longlong(lower[c]) && !(want == 0.0 && lower[c] == 0.0)) bad = true;
+    }
+    if (bad) atomicOr(flag, 1);
 }
 
 // ---- building the offset code book (set-up) ---------------------------------------------------
@@ -636,13 +778,15 @@ struct FusedRestrictArgs {
     const double* x;        // fine iterate, base of storage
     const double* f;        // fine right-hand side, row-based
     double* fc;             // coarse right-hand side, base of storage
-    int W, R, coded;
+    int W, R, coded;        // coded: 0 int32 columns, 1 offset codes, 2 symmetric diagonals (W = WU)
+    int up[8];
+    int64_t mlead;
     Grid gc, gf;
 };
 
 __global__ void residual_inject(FusedRestrictArgs a) {
     __shared__ int s_off[256];
-    if (a.coded) {
+    if (a.coded == 1) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x) s_off[t] = a.offsets[t];
         __syncthreads();
     }
@@ -656,7 +800,17 @@ __global__ void residual_inject(FusedRestrictArgs a) {
     const int64_t slice = row / S, within = row % S;
     const size_t base = (size_t)slice * a.W * S + within;
     double acc = 0.0;
-    if (a.coded) {
+    if (a.coded == 2) {
+        const int64_t m = row + a.mlead;
+        const double* xrow = a.x + a.gf.lead + row;
+        for (int c = a.W - 1; c >= 1; --c) {
+            const int64_t mm = m - a.up[c];
+            acc = fma(a.vals[((size_t)(mm / S) * a.W + c) * S + (size_t)(mm % S)], xrow[-a.up[c]], acc);
+        }
+        const size_t mb = (size_t)(m / S) * a.W * S + (size_t)(m % S);
+        acc = fma(a.vals[mb], xrow[0], acc);
+        for (int c = 1; c < a.W; ++c) acc = fma(a.vals[mb + (size_t)c * S], xrow[a.up[c]], acc);
+    } else if (a.coded) {
         const int CW = (a.W + 7) / 8;
         const size_t cbase = (size_t)slice * CW * S + within;
         const double* xrow = a.x + a.gf.lead + row;

@@ -78,7 +78,8 @@ class DeviceHierarchy:
     def __init__(self, dim: int, coarsest_level: int, finest_level: int, c: int = 8, device: int = 0,
                  rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
                  offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
-                 nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None):
+                 nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None,
+                 symmetric_storage: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -100,6 +101,8 @@ class DeviceHierarchy:
             self.set_tuning("nontemporal", nontemporal)
         if coarse_direct is not None:
             self.set_tuning("coarse_direct", coarse_direct)
+        if symmetric_storage is not None:
+            self.set_tuning("symmetric_storage", symmetric_storage)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):
@@ -258,7 +261,8 @@ class DeviceHierarchy:
         out = {k: int(v.value) for k, v in zip(keys, vals)}
         out["ell_width"] = int(w.value)
         out["replicated"] = bool(rep.value)
-        out["offset_codes"] = int(codes.value)
+        out["offset_codes"] = max(0, int(codes.value))
+        out["symmetric_diagonals"] = max(0, -int(codes.value))
         return out
 
     def memory_bytes(self) -> int:

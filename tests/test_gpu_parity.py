@@ -292,10 +292,13 @@ def test_device_generator_equals_csr_hand_off(dim, lo, hi, c):
             assert a.level_info(hi)["nnz_nonzero"] == int((bag.levels[hi].A.data != 0).sum())
 
 
-@pytest.mark.parametrize("dim,lo,hi,c", [(2, 2, 4, 8), (3, 1, 3, 4)])
-def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c):
+@pytest.mark.parametrize("dim,lo,hi,c,seed", [(2, 2, 4, 8, 9), (3, 1, 3, 4, 9), (2, 2, 4, 8, None), (3, 1, 3, 4, None)])
+def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c, seed):
+    """Three matrix formats x rows per lane x block map x pruning.  The int32-column and offset-coded
+    kernels add a row's entries in the order the caller stored them, the symmetric-diagonal kernel in
+    ascending grid order: bit-identical for lexicographic inputs (seed None), round-off otherwise."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
-    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=4, mu2=4, seed=9)
+    bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=4, mu2=4, seed=seed)
     gi = {l: L.grid_index for l, L in bag.levels.items()}
     f = bag.b_dict[hi]
     base = None
@@ -305,15 +308,23 @@ def test_tile_shape_and_pruning_do_not_change_results(dim, lo, hi, c):
                 with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
                                               xcd_chunk=chunk) as dev:
                     out = _one_cycle(dev, hi, f)
-                    assert dev.level_info(hi)["offset_codes"] in (5, 7, 15)       # coded columns in use
+                    info = dev.level_info(hi)
+                    assert info["symmetric_diagonals"] in (3, 4, 8) and info["offset_codes"] == 0
                 if chunk == 1:
-                    # int32 column indices + streamed D^-1: same arithmetic, bit for bit
-                    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
-                                                  xcd_chunk=chunk, offset_codes=0) as dev:
-                        assert dev.level_info(hi)["offset_codes"] == 0
-                        assert np.array_equal(_one_cycle(dev, hi, f), out), (prune, R)
+                    others = []
+                    for kw, codes in ((dict(symmetric_storage=0), (5, 7, 15)), (dict(offset_codes=0), (0,))):
+                        with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, prune_zeros=prune, rows_per_lane=R,
+                                                      xcd_chunk=chunk, **kw) as dev:
+                            info = dev.level_info(hi)
+                            assert info["offset_codes"] in codes and info["symmetric_diagonals"] == 0
+                            others.append(_one_cycle(dev, hi, f))
+                    assert np.array_equal(others[0], others[1]), (prune, R)        # same order of additions
+                    if seed is None:
+                        assert np.array_equal(others[0], out), (prune, R)
+                    else:
+                        assert rel_l2(others[0], out) <= 1e-13, (prune, R)
                 # the tile shape changes which rows share a block, hence the order of the partial
-                # sums in the coarse solver's dot products: equal to round-off, not bit for bit
+                # sums in dot products; pruning removes exact zeros: equal to round-off, not bit for bit
                 if base is None:
                     base = out
                 else:
@@ -440,22 +451,23 @@ def test_traversal_order_and_streaming_loads_do_not_change_results():
 def test_headline_size_checksums_agree_between_formats():
     """BASELINE config C4 at full size (1025^3 unknowns, 6 levels, one GPU).  Vectors of this size never
     cross to the host; the check is a checksum of checksums: the l2 residual norms of three V(2,2) cycles
-    must fall monotonically and agree between the two matrix formats (offset-coded columns with in-kernel
-    D^-1 vs int32 columns with streamed D^-1), which share nothing but the arithmetic."""
+    must fall monotonically and agree between the three matrix formats (symmetric diagonals, offset-coded
+    columns with in-kernel D^-1, int32 columns with streamed D^-1), which share nothing but the arithmetic."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     norms = []
-    for codes in (1, 0):
-        with DeviceHierarchy.synthetic(3, 2, 7, c=8, mu1=2, mu2=2, offset_codes=codes) as dev:
+    for kw, want in ((dict(), (0, 4)), (dict(symmetric_storage=0), (7, 0)), (dict(offset_codes=0), (0, 0))):
+        with DeviceHierarchy.synthetic(3, 2, 7, c=8, mu1=2, mu2=2, **kw) as dev:
             info = dev.level_info(7)
             assert info["n_global"] == 1025 ** 3 and info["ell_width"] == 7
-            assert (info["offset_codes"] == 7) == bool(codes)
+            assert (info["offset_codes"], info["symmetric_diagonals"]) == want
             assert info["nnz_nonzero"] == 7 * 1023 ** 3 - 6 * 1023 ** 2 + (1025 ** 3 - 1023 ** 3)
             f_norm = dev.norm2(7, "f")
             dev.zero_vector(7, "v")
             res = dev.vcycle(7, 3, residuals=True)
             assert res[0] < f_norm and res[1] < res[0] and res[2] < res[1]
             norms.append(np.concatenate([[f_norm], res]))
-    assert np.all(np.abs(norms[0] - norms[1]) <= 1e-12 * norms[1])
+    for other in norms[1:]:
+        assert np.all(np.abs(norms[0] - other) <= 1e-12 * other)
 
 
 @pytest.mark.parametrize("dim,lo,hi,c,seed", [(2, 1, 3, 8, 4), (3, 1, 3, 2, None), (3, 1, 3, 4, 6)])
@@ -529,12 +541,34 @@ def test_fused_residual_injection_is_bit_identical(dim, lo, hi, c):
     bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=3, mu2=3, seed=12)
     gi = {l: L.grid_index for l, L in bag.levels.items()}
     f = bag.b_dict[hi]
-    for codes in (1, 0):
+    for kw in (dict(), dict(symmetric_storage=0), dict(offset_codes=0)):
         outs = []
         for fused in (1, 0):
-            with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, offset_codes=codes) as dev:
+            with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, **kw) as dev:
                 dev.set_tuning("fuse_restrict", fused)
                 v = _one_cycle(dev, hi, f)
                 outs.append((v, dev.get_vector(hi - 1, "f"), dev.get_vector(hi - 1, "v")))
         for a, b in zip(*outs):
             assert np.array_equal(a, b)
+
+
+def test_asymmetric_matrix_keeps_full_storage():
+    """Symmetric diagonal storage must only be chosen for bit-for-bit symmetric matrices."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(2, 1, 2, c=8, mu1=2, mu2=2)
+    A = bag.A_sp_dict[2][0].copy()
+    rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    upper = (A.indices > rows) & (A.data != 0)
+    A.data[np.flatnonzero(upper)[7]] *= 1.0 + 2.0 ** -50          # one entry, last bits only
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((A.shape[0], 1))
+    with DeviceHierarchy(2, 1, 2, c=8) as dev:
+        dev.set_level(1, bag.A_sp_dict[1][0], bag.levels[1].grid_index)
+        dev.set_level(2, A, bag.levels[2].grid_index)
+        info = dev.level_info(2)
+        assert info["symmetric_diagonals"] == 0 and info["offset_codes"] == 5
+        dev.set_params(2, 2, 2 / 3)
+        dev.set_vector(2, "v", v)
+        dev.set_vector(2, "f", bag.b_dict[2])
+        dev.residual(2)
+        assert rel_l2(dev.get_vector(2, "r"), bag.b_dict[2] - A.dot(v)) <= 1e-14
