@@ -168,7 +168,7 @@ struct mg_context {
     // tuning
     int use_codes = 1;          // offset-coded columns where a level allows it
     int use_sdia = 1;           // symmetric diagonal storage where a level is bit-for-bit symmetric
-    int strip_slices = 0;       // XCD strip traversal for 3-D levels (0 = chunked map only; measured: no gain)
+    int strip_slices = 64;      // XCD strip traversal for 3-D levels (0 = chunked map only)
     int nontemporal = 1;        // streaming loads for matrix / rhs data
     int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
     unsigned chunk = 8;         // XCD chunk of the block -> tile map
@@ -225,8 +225,9 @@ constexpr int64_t kVecSlack = 260;
 
 inline int64_t vec_reach(const Level& L) { return L.flat ? 0 : L.g.plane + L.g.nx + 4; }
 inline int64_t vec_front(const Level& L) {
-    const int64_t slack = ((vec_reach(L) + 3) / 4) * 4;
-    return slack + (4 - (L.g.lead % 4)) % 4;
+    // the first owned row starts a 128-byte line (hipMalloc returns 256-byte aligned memory)
+    const int64_t slack = ((vec_reach(L) + 15) / 16) * 16;
+    return slack + (16 - (L.g.lead % 16)) % 16;
 }
 inline int64_t vec_total(const Level& L) { return vec_front(L) + L.xlen + kVecSlack + vec_reach(L); }
 
@@ -453,9 +454,26 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
     a.color = color; a.parity0 = (int)(L.row0 & 1);
     unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
+    // XCD strip traversal (optional): pays when a plane is much larger than a strip
+    auto plan_strips = [&]() {
+        const int64_t ps4 = (L.g.plane / (WAVE * L.R)) / 4;            // blocks per pseudo-plane
+        const int64_t want = c->strip_slices / 4;                       // blocks per strip asked for
+        if (!(whole && want > 0 && !dot && L.g.nz > 1 && ps4 >= 16 * want)) return;
+        const int64_t m = std::max<int64_t>(1, (ps4 + 4 * want) / (8 * want));     // round(ps4 / want / 8)
+        const int64_t ns = 8 * m;
+        const int64_t nblocks = (L.nslices + 3) / 4;
+        const int64_t kp = (nblocks + ps4 - 1) / ps4;
+        const int64_t bmax = (ps4 + ns - 1) / ns;
+        const int64_t g = ns * kp * bmax;
+        if (g < ((int64_t)1 << 31) && kp < ((int64_t)1 << 31)) {
+            a.strip_ns = (unsigned)ns; a.strip_bmax = (unsigned)bmax; a.ps4 = (unsigned)ps4; a.kp = (unsigned)kp;
+            grid = (unsigned)g;
+        }
+    };
     if (L.sdia) {
         a.vals = L.dvals; a.mlead = L.mlead;
         for (int t = 0; t < 8; ++t) a.up[t] = L.up[t];
+        plan_strips();
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
         switch (L.R) {
@@ -468,21 +486,7 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         return 0;
     }
     if (L.coded) {
-        // strip traversal pays when a plane is much larger than a strip (3-D levels beyond L2 reach)
-        const int64_t ps4 = (L.g.plane / (WAVE * L.R)) / 4;            // blocks per pseudo-plane
-        const int64_t want = c->strip_slices / 4;                       // blocks per strip asked for
-        if (whole && want > 0 && !dot && L.g.nz > 1 && ps4 >= 16 * want) {
-            const int64_t m = std::max<int64_t>(1, (ps4 + 4 * want) / (8 * want));     // round(ps4 / want / 8)
-            const int64_t ns = 8 * m;
-            const int64_t nblocks = (L.nslices + 3) / 4;
-            const int64_t kp = (nblocks + ps4 - 1) / ps4;
-            const int64_t bmax = (ps4 + ns - 1) / ns;
-            const int64_t g = ns * kp * bmax;
-            if (g < ((int64_t)1 << 31) && kp < ((int64_t)1 << 31)) {
-                a.strip_ns = (unsigned)ns; a.strip_bmax = (unsigned)bmax; a.ps4 = (unsigned)ps4; a.kp = (unsigned)kp;
-                grid = (unsigned)g;
-            }
-        }
+        plan_strips();
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
         switch (L.R) {
@@ -782,7 +786,7 @@ int build_direct(mg_context* c) {
     if (p > 2048 || nb * p * p * 8 > ((int64_t)3 << 29)) return 0;     // too large to store densely: PCG
     d.g.n = L.nloc; d.g.p = (int)p; d.g.plane = (int)plane; d.g.nb = (int)nb; d.g.W = L.W;
     const size_t pw = (size_t)nb * p * L.W, np = (size_t)nb * p, pp = (size_t)p * p;
-    double *A = nullptr, *B = nullptr;
+    double *A = nullptr, *B = nullptr, *P = nullptr;       // A: block being inverted, B: row panel, P: pivot block
     int* d_status = nullptr;
     int rc = [&]() -> int {
         MG_TRY(dev_alloc(c, &d.T, np * p));
@@ -790,12 +794,13 @@ int build_direct(mg_context* c) {
         MG_TRY(dev_alloc(c, &d.lval, pw)); MG_TRY(dev_alloc(c, &d.uval, pw));
         MG_TRY(dev_alloc(c, &d.y, np)); MG_TRY(dev_alloc(c, &d.x, np)); MG_TRY(dev_alloc(c, &d.w, (size_t)p));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&A), pp * 8));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&B), pp * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&B), (size_t)GJ_NB * p * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&P), (size_t)GJ_NB * GJ_NB * 8));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_status), sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), c->stream));
         const EllView e = ell_view(L);
         const dim3 rows_grid(blocks_for(p, 128)), rows_blk(128);
-        const dim3 gj_grid(blocks_for(p, 256), (unsigned)p), gj_blk(256);
+        const dim3 gj_blk(256);
         for (int k = 0; k < (int)nb; ++k) {
             const size_t ko = (size_t)k * p * L.W;
             HIP_TRY(hipMemsetAsync(A, 0, pp * 8, c->stream));
@@ -807,13 +812,17 @@ int build_direct(mg_context* c) {
                 hipLaunchKernelGGL(bt_schur_update, rows_grid, rows_blk, 0, c->stream, d.g, d.lcol + ko, d.lval + ko,
                                    d.ucol + po, d.uval + po, d.T + (size_t)(k - 1) * pp, A);
             }
-            double *in = A, *out = B;
-            for (int piv = 0; piv < (int)p; ++piv) {
-                hipLaunchKernelGGL(bt_gauss_jordan_step, gj_grid, gj_blk, 0, c->stream, (int)p, piv, in, out);
-                std::swap(in, out);
+            for (int k0 = 0; k0 < (int)p; k0 += GJ_NB) {
+                const int nbk = std::min<int>(GJ_NB, (int)p - k0);
+                hipLaunchKernelGGL(gj_pivot_block, dim3(1), gj_blk, 0, c->stream, (int)p, k0, nbk, A, P);
+                hipLaunchKernelGGL(gj_row_panel, dim3(blocks_for(p, 256), (unsigned)nbk), gj_blk, 0, c->stream, (int)p, k0,
+                                   nbk, A, P, B);
+                hipLaunchKernelGGL(gj_trailing, dim3(blocks_for(p, 256), (unsigned)p), gj_blk, 0, c->stream, (int)p, k0, nbk,
+                                   A, B);
+                hipLaunchKernelGGL(gj_finish, dim3(blocks_for(p, 128)), dim3(128), 0, c->stream, (int)p, k0, nbk, A, P, B);
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(d.T + (size_t)k * pp, in, pp * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d.T + (size_t)k * pp, A, pp * 8, hipMemcpyDeviceToDevice, c->stream));
         }
         int status = 0;
         HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -821,7 +830,7 @@ int build_direct(mg_context* c) {
         d.ok = status == 0;
         return 0;
     }();
-    (void)hipFree(A); (void)hipFree(B); (void)hipFree(d_status);
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(P); (void)hipFree(d_status);
     if (rc || !d.ok) { free_direct(c); d.tried = true; }
     return rc;
 }

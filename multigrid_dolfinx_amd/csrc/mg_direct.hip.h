@@ -108,20 +108,79 @@ __global__ void bt_schur_update(BtGeom g, const int* __restrict__ lcol, const do
     }
 }
 
-// One Gauss-Jordan pivot step of the in-place inverse, read from `in`, written to `out`.
-__global__ void bt_gauss_jordan_step(int p, int piv, const double* __restrict__ in, double* __restrict__ out) {
+// ---- blocked in-place Gauss-Jordan inverse (no pivoting), GJ_NB pivots per round of 4 launches -----
+// Round with pivot rows/columns K = [k0, k0+nb):
+//   1. gj_pivot_block   P  = A[K,K]^-1                         (one workgroup, in LDS)
+//   2. gj_row_panel     RP = P A[K,:]
+//   3. gj_trailing      A[I,J] -= A[I,K] RP[:,J]               for I, J outside K
+//   4. gj_finish        A[I,K] = -A[I,K] P (I outside K);  A[K,J] = RP[:,J] (J outside K);  A[K,K] = P
+constexpr int GJ_NB = 32;
+
+__global__ __launch_bounds__(256) void gj_pivot_block(int p, int k0, int nb, const double* __restrict__ A,
+                                                        double* __restrict__ P) {
+    __shared__ double s[GJ_NB][GJ_NB + 1];
+    for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) s[t / nb][t % nb] = A[(size_t)(k0 + t / nb) * p + k0 + t % nb];
+    __syncthreads();
+    for (int piv = 0; piv < nb; ++piv) {
+        const double pivot = 1.0 / s[piv][piv];
+        __syncthreads();
+        double upd[(GJ_NB * GJ_NB + 255) / 256];
+        int cnt = 0;
+        for (int t = threadIdx.x; t < nb * nb; t += blockDim.x, ++cnt) {
+            const int i = t / nb, j = t % nb;
+            double o;
+            if (i == piv) o = (j == piv) ? pivot : s[i][j] * pivot;
+            else {
+                const double f = s[i][piv];
+                o = (j == piv) ? -f * pivot : s[i][j] - f * (s[piv][j] * pivot);
+            }
+            upd[cnt] = o;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int t = threadIdx.x; t < nb * nb; t += blockDim.x, ++cnt) s[t / nb][t % nb] = upd[cnt];
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) P[t] = s[t / nb][t % nb];
+}
+
+__global__ void gj_row_panel(int p, int k0, int nb, const double* __restrict__ A, const double* __restrict__ P,
+                             double* __restrict__ RP) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= p) return;
-    const double pivot = 1.0 / in[(size_t)piv * p + piv];
-    const double mij = in[(size_t)i * p + j];
-    double o;
-    if (i == piv) o = (j == piv) ? pivot : mij * pivot;
-    else {
-        const double f = in[(size_t)i * p + piv];
-        o = (j == piv) ? -f * pivot : mij - f * (in[(size_t)piv * p + j] * pivot);
+    double acc = 0.0;
+    for (int t = 0; t < nb; ++t) acc = fma(P[i * nb + t], A[(size_t)(k0 + t) * p + j], acc);
+    RP[(size_t)i * p + j] = acc;
+}
+
+__global__ void gj_trailing(int p, int k0, int nb, double* __restrict__ A, const double* __restrict__ RP) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= p || (i >= k0 && i < k0 + nb) || (j >= k0 && j < k0 + nb)) return;
+    const double* Ai = A + (size_t)i * p;
+    double acc = Ai[j];
+    for (int t = 0; t < nb; ++t) acc = fma(-Ai[k0 + t], RP[(size_t)t * p + j], acc);
+    A[(size_t)i * p + j] = acc;
+}
+
+__global__ void gj_finish(int p, int k0, int nb, double* __restrict__ A, const double* __restrict__ P,
+                          const double* __restrict__ RP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    double* Ai = A + (size_t)i * p;
+    if (i >= k0 && i < k0 + nb) {
+        const int r = i - k0;
+        for (int j = 0; j < p; ++j) Ai[j] = (j >= k0 && j < k0 + nb) ? P[r * nb + (j - k0)] : RP[(size_t)r * p + j];
+    } else {
+        double old[GJ_NB];
+        for (int t = 0; t < nb; ++t) old[t] = Ai[k0 + t];
+        for (int j = 0; j < nb; ++j) {
+            double acc = 0.0;
+            for (int t = 0; t < nb; ++t) acc = fma(old[t], P[t * nb + j], acc);
+            Ai[k0 + j] = -acc;
+        }
     }
-    out[(size_t)i * p + j] = o;
 }
 
 // Forward step k >= 1: y_k = b_k - L_k (T_{k-1} y_{k-1}); one wave per row, rows without a coupling copy b.

@@ -34,6 +34,9 @@ constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 template <int R> struct alignas(8 * R) DVec { double d[R]; };
 template <int R> struct alignas(4 * R) IVec { int d[R]; };
 template <int R> struct alignas(8 * R) UVec { unsigned long long d[R]; };
+// R consecutive doubles at an address that is only 8-byte aligned (shifted stencil accesses): one
+// global_load_dwordx4 for R = 2 instead of two dwordx2 loads.
+template <int R> struct alignas(8) DVecU { double d[R]; };
 
 // MODE_GS: in-place relaxation of the rows of one colour (red-black Gauss-Seidel half sweep);
 // the colour of a row is the parity of its global lexicographic index, a valid two-colouring of
@@ -305,7 +308,14 @@ __global__ __launch_bounds__(BLOCK) void sdia_apply(EllArgs a) {
     constexpr int S = WAVE * R;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    int64_t sl;
+    if (a.strip_ns) {
+        const int64_t first = strip_block(a, blockIdx.x);
+        if (!DOT && first < 0) return;
+        sl = first < 0 ? a.nslices : first + wave;
+    } else {
+        sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    }
     double dot = 0.0;
     if (sl < a.nslices) {
         const int64_t slice = a.slice0 + sl;
@@ -319,26 +329,37 @@ __global__ __launch_bounds__(BLOCK) void sdia_apply(EllArgs a) {
         up[0] = load_d<R, NT>(a.vals + base);
 #pragma unroll
         for (int c = 1; c < WU; ++c) up[c] = load_d<R, false>(a.vals + base + (size_t)c * S);
-        double lo[WU][R];
+        // the lower entries and the x neighbours of a lane's R rows are R consecutive doubles at shifted
+        // (8-byte aligned) addresses: one unaligned vector load each, unless the run crosses a slice
+        DVecU<R> lo[WU], xl[WU], xu[WU];
 #pragma unroll
         for (int c = 1; c < WU; ++c) {
+            const int64_t mm = m - a.up[c];
+            const int64_t in = mm % S;
+            if (in + R <= S) {
+                lo[c] = *reinterpret_cast<const DVecU<R>*>(a.vals + ((size_t)(mm / S) * WU + c) * S + (size_t)in);
+            } else {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t mm = m + r - a.up[c];
-                lo[c][r] = a.vals[((size_t)(mm / S) * WU + c) * S + (size_t)(mm % S)];
+                for (int r = 0; r < R; ++r) {
+                    const int64_t m2 = mm + r;
+                    lo[c].d[r] = a.vals[((size_t)(m2 / S) * WU + c) * S + (size_t)(m2 % S)];
+                }
             }
+            xl[c] = *reinterpret_cast<const DVecU<R>*>(xrow - a.up[c]);
+            xu[c] = *reinterpret_cast<const DVecU<R>*>(xrow + a.up[c]);
         }
+        const DVec<R> x0 = *reinterpret_cast<const DVec<R>*>(xrow);
         double acc[R], diag[R], xr[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             acc[r] = 0.0;
 #pragma unroll
-            for (int c = WU - 1; c >= 1; --c) acc[r] = fma(lo[c][r], xrow[r - a.up[c]], acc[r]);
-            xr[r] = xrow[r];
+            for (int c = WU - 1; c >= 1; --c) acc[r] = fma(lo[c].d[r], xl[c].d[r], acc[r]);
+            xr[r] = x0.d[r];
             diag[r] = up[0].d[r] != 0.0 ? up[0].d[r] : 1.0;
             acc[r] = fma(up[0].d[r], xr[r], acc[r]);
 #pragma unroll
-            for (int c = 1; c < WU; ++c) acc[r] = fma(up[c].d[r], xrow[r + a.up[c]], acc[r]);
+            for (int c = 1; c < WU; ++c) acc[r] = fma(up[c].d[r], xu[c].d[r], acc[r]);
         }
         tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
     }

@@ -7,11 +7,12 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 
 def trace(d, out):
-    path = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
+    path = max(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
@@ -25,7 +26,7 @@ def trace(d, out):
 
 
 def pmc(d, out):
-    path = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    path = max(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         agg[(r["Kernel_Name"], int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
