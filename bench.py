@@ -209,7 +209,9 @@ def main():
     jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
     res_ms = h.time_kernel("residual", hi, args.kernel_reps)
     n_loc, z_loc = info["n_local"], info["nnz_nonzero"]
-    bytes_jacobi = 12 * z_loc + 32 * n_loc                   # values+columns, read v f D^-1, write v (no row pointers)
+    # ALGORITHMIC bytes (ELL form): values + int32 columns, read v f D^-1, write v -- what a
+    # plain ELL sweep moves; the shipped formats move less (see roofline.traffic and DESIGN.md section 5)
+    bytes_jacobi = 12 * z_loc + 32 * n_loc
     bytes_resid = 12 * z_loc + 24 * n_loc
     achieved = bytes_jacobi / (jac_ms * 1e-3) / 1e9
     traffic = None
@@ -239,14 +241,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "
-                                   f"omega={args.omega:.4f}, injection, Q1 prolongation, PCG coarsest solve, "
+                                   f"omega={args.omega:.4f}, injection, Q1 prolongation, exact block-LU coarsest solve, "
                                    f"explicit zeros pruned (7-point rows)" if dim == 3 else
                                    f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi",
                        "levels": hi - lo + 1, "dim": dim, "elements_per_dim": 8 * 2 ** hi,
                        "parallelism": f"slab{args.gpus}" if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ell_apply<W,R,JACOBI> (fine-level weighted-Jacobi sweep)",
+                         "kernel": ("sdia_apply" if info["symmetric_diagonals"] else
+                                    "ell_apply_coded" if info["offset_codes"] else "ell_apply")
+                                   + "<..., MODE_JACOBI> (fine-level weighted-Jacobi sweep)",
+                         "storage": ("symmetric diagonals" if info["symmetric_diagonals"] else
+                                     "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
                          "kernel_ms": jac_ms, "algorithmic_bytes_per_launch": bytes_jacobi,
                          "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
                          "residual_kernel_ms": res_ms,
