@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--nontemporal", type=int, default=None)
     ap.add_argument("--coarse-direct", type=int, default=None, help="0 = PCG on the coarsest level")
     ap.add_argument("--symmetric-storage", type=int, default=None, help="0 = keep lower entries and codes")
+    ap.add_argument("--graph", type=int, default=None, help="0 = launch every kernel of a V-cycle eagerly")
     ap.add_argument("--replicate-below", type=int, default=1 << 22,
                     help="levels with fewer unknowns are replicated on every rank")
     ap.add_argument("--kernel-reps", type=int, default=20)
@@ -131,6 +132,8 @@ def build_hierarchy(args, rv):
         tuning["coarse_direct"] = args.coarse_direct
     if args.symmetric_storage is not None:
         tuning["symmetric_storage"] = args.symmetric_storage
+    if args.graph is not None:
+        tuning["graph"] = args.graph
 
     def comm(h):
         if rv.world == 1:

@@ -152,6 +152,15 @@ struct DirectSolver {
     double *y = nullptr, *x = nullptr, *w = nullptr;
 };
 
+// One captured V-cycle (hipGraph): valid for a level, a parameter epoch and a ping-pong state.
+struct CycleGraph {
+    int level = -1;
+    uint64_t epoch = 0;
+    std::vector<double*> pre, post;     // raw pointer of MG_VEC_V on levels 0..level before / after the cycle
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct mg_context {
     int dim = 2, nlev = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -182,6 +191,9 @@ struct mg_context {
     DVector pcg_p;
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
+    int use_graph = 1;              // replay whole V-cycles as hipGraphs (single GPU, direct coarsest solve)
+    uint64_t epoch = 1;             // bumped by every call that changes what a V-cycle launches
+    std::vector<CycleGraph> graphs;
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
@@ -337,7 +349,11 @@ int alloc_level_vectors(mg_context* c, Level& L) {
 
 void free_direct(mg_context* c);
 
+void drop_graphs(mg_context* c);
+
 void free_level(mg_context* c, Level& L) {
+    ++c->epoch;
+    drop_graphs(c);
     if (&L == &c->L[0]) free_direct(c);
     if (!L.set && !L.vals) return;
     const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
@@ -944,6 +960,53 @@ int vcycle(mg_context* c, int level) {
     return 0;
 }
 
+void drop_graphs(mg_context* c) {
+    for (auto& g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
+}
+
+// A V-cycle is a fixed sequence of launches once the coarsest solve is the direct one (no host round
+// trip), so it is captured into a hipGraph the first time and replayed afterwards: the launch-bound coarse
+// levels then cost a kernel boundary instead of a host launch each.  The Jacobi ping-pong swaps the
+// MG_VEC_V buffers mu1+mu2 times per level; the captured pointer state is part of the cache key and the
+// swaps are re-applied on the host after a replay.
+int vcycle_graphed(mg_context* c, int level) {
+    if (!c->direct.tried) MG_TRY(build_direct(c));
+    if (!c->use_graph || c->comm.active() || level == 0 || !c->direct.ok) return vcycle(c, level);
+    if (c->keep_err)
+        for (int l = 1; l <= level; ++l) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].err));
+    std::vector<double*> pre(level + 1);
+    for (int l = 0; l <= level; ++l) pre[l] = c->L[l].v.raw;
+    for (auto& g : c->graphs) {
+        if (g.level != level || g.epoch != c->epoch || g.pre != pre) continue;
+        HIP_TRY(hipGraphLaunch(g.exec, c->stream));
+        for (int l = 0; l <= level; ++l)
+            if (c->L[l].v.raw != g.post[l]) std::swap(c->L[l].v, c->L[l].v2);
+        return 0;
+    }
+    if (c->graphs.size() >= 8) drop_graphs(c);
+    CycleGraph g;
+    g.level = level; g.epoch = c->epoch; g.pre = pre;
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = vcycle(c, level);
+    const hipError_t e = hipStreamEndCapture(c->stream, &g.graph);
+    if (rc != 0 || e != hipSuccess) {
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        (void)hipGetLastError();
+        if (rc != 0) return rc;
+        return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    g.post.resize(level + 1);
+    for (int l = 0; l <= level; ++l) g.post[l] = c->L[l].v.raw;
+    HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(g.exec, c->stream));
+    c->graphs.push_back(std::move(g));
+    return 0;
+}
+
 int ensure_stage(mg_context* c, int64_t elems) {
     if (c->stage_elems >= elems) return 0;
     dev_free(c, c->stage, (size_t)c->stage_elems);
@@ -1173,6 +1236,7 @@ int mg_destroy(mg_handle c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    drop_graphs(c);
     for (auto& L : c->L) free_level(c, L);
     (void)hipFree(c->partials);
     (void)hipFree(c->scalars);
@@ -1287,6 +1351,7 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
     if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
     if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
     if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS) return fail("unknown smoother");
+    ++c->epoch;
     c->mu1 = mu1; c->mu2 = mu2; c->omega = omega; c->restriction = restriction; c->smoother = smoother;
     if (coarse_rtol > 0) c->coarse_rtol = coarse_rtol;
     if (coarse_maxit > 0) c->coarse_maxit = coarse_maxit;
@@ -1296,7 +1361,12 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
 
 int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     if (!c || !key) return fail("bad arguments");
+    ++c->epoch;
     const std::string k(key);
+    if (k == "graph") {
+        c->use_graph = value != 0;
+        return 0;
+    }
     if (k == "rows_per_lane") {
         if (value != 1 && value != 2 && value != 4) return fail("rows_per_lane must be 1, 2 or 4");
         for (auto& L : c->L)
@@ -1720,7 +1790,7 @@ int mg_vcycle(mg_handle c, int level, int ncycles, double* resid_l2) {
     Level& L = c->L[level];
     MG_TRY(exchange_halo(c, L, L.v));
     for (int k = 0; k < ncycles; ++k) {
-        MG_TRY(vcycle(c, level));
+        MG_TRY(vcycle_graphed(c, level));
         if (resid_l2) {
             MG_TRY(residual(c, level));
             MG_TRY(norm2(c, L, L.v2.rows, &resid_l2[k]));

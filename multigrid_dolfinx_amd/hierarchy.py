@@ -79,7 +79,7 @@ class DeviceHierarchy:
                  rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
                  offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
                  nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None,
-                 symmetric_storage: Optional[int] = None):
+                 symmetric_storage: Optional[int] = None, graph: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -103,6 +103,8 @@ class DeviceHierarchy:
             self.set_tuning("coarse_direct", coarse_direct)
         if symmetric_storage is not None:
             self.set_tuning("symmetric_storage", symmetric_storage)
+        if graph is not None:
+            self.set_tuning("graph", graph)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):

@@ -572,3 +572,26 @@ def test_asymmetric_matrix_keeps_full_storage():
         dev.set_vector(2, "f", bag.b_dict[2])
         dev.residual(2)
         assert rel_l2(dev.get_vector(2, "r"), bag.b_dict[2] - A.dot(v)) <= 1e-14
+
+
+@pytest.mark.parametrize("mu", [(2, 2), (3, 2), (1, 0)])
+def test_graph_replay_equals_eager_launches(mu):
+    """V-cycles are captured into a hipGraph and replayed; the Jacobi ping-pong state (odd sweep totals swap
+    the buffers) is part of the cache key.  Five cycles must equal five eagerly launched ones bit for bit."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(2, 1, 3, c=8, mu1=mu[0], mu2=mu[1], seed=7)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    f = bag.b_dict[3]
+    outs = []
+    for graph in (1, 0):
+        with DeviceHierarchy.from_bag(bag, dim=2, grid_index=gi, graph=graph) as dev:
+            dev.set_vector(3, "v", np.zeros_like(f))
+            dev.set_vector(3, "f", f)
+            res = []
+            for _ in range(5):
+                res.append(dev.vcycle(3, 1, residuals=True)[0])
+            dev.set_params(mu[0] + 1, mu[1], bag.omega, keep_err=True)      # new parameters: a new capture
+            dev.vcycle(3, 2)
+            outs.append((dev.get_vector(3, "v"), np.array(res), dev.get_vector(3, "err"), dev.get_vector(2, "f")))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
