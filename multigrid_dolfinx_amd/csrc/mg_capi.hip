@@ -1406,54 +1406,68 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     return 0;
 }
 
-int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
-                     const int32_t* indices, const double* data, const int64_t* grid_index, int prune_zeros) {
-    MG_TRY(check_level(c, level, false));
-    if (!indptr || !indices || !data) return fail("null CSR arrays");
-    HIP_TRY(hipSetDevice(c->device));
-    Level& L = c->L[level];
-    free_level(c, L);
-    MG_TRY(setup_geometry(c, level, N, n_rows));
-    if (n_rows != L.n_global)
-        return fail("matrix has " + std::to_string(n_rows) + " rows, grid has " + std::to_string(L.n_global));
-    // upload the hand-off
-    void* d_ptr = nullptr;
-    int* d_idx = nullptr;
-    double* d_val = nullptr;
-    const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
-    HIP_TRY(hipMalloc(&d_ptr, ptr_bytes));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), std::max<size_t>(1, (size_t)nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_val), std::max<size_t>(1, (size_t)nnz) * 8));
-    auto cleanup = [&]() { (void)hipFree(d_ptr); (void)hipFree(d_idx); (void)hipFree(d_val); };
-    HIP_TRY(hipMemcpyAsync(d_ptr, indptr, ptr_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_idx, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_val, data, (size_t)nnz * 8, hipMemcpyHostToDevice, c->stream));
-    if (grid_index) {
-        std::vector<int> p32((size_t)n_rows);
-        std::vector<char> seen((size_t)n_rows, 0);
-        for (int64_t d = 0; d < n_rows; ++d) {
-            const int64_t p = grid_index[d];
-            if (p < 0 || p >= n_rows || seen[(size_t)p]) { cleanup(); return fail("grid_index is not a permutation of the grid nodes"); }
-            seen[(size_t)p] = 1;
-            p32[(size_t)d] = (int)p;
-        }
-        if (dev_alloc(c, &L.perm, (size_t)n_rows)) { cleanup(); return 1; }
-        HIP_TRY(hipMemcpy(L.perm, p32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+namespace {
+
+// Temporary device buffer that frees itself (set-up paths have many early exits).
+struct DevTemp {
+    void* p = nullptr;
+    DevTemp() = default;
+    DevTemp(const DevTemp&) = delete;
+    DevTemp& operator=(const DevTemp&) = delete;
+    ~DevTemp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(1, bytes)));
+        return 0;
     }
+};
+
+// grid_index[dof] (int64, caller) -> L.perm (int32, device), validated as a permutation of the nodes.
+int upload_permutation(mg_context* c, Level& L, const int64_t* grid_index, int64_t n_rows) {
+    if (!grid_index) return 0;
+    std::vector<int> p32((size_t)n_rows);
+    std::vector<char> seen((size_t)n_rows, 0);
+    for (int64_t d = 0; d < n_rows; ++d) {
+        const int64_t p = grid_index[d];
+        if (p < 0 || p >= n_rows || seen[(size_t)p]) return fail("grid_index is not a permutation of the grid nodes");
+        seen[(size_t)p] = 1;
+        p32[(size_t)d] = (int)p;
+    }
+    MG_TRY(dev_alloc(c, &L.perm, (size_t)n_rows));
+    HIP_TRY(hipMemcpy(L.perm, p32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int64_t nnz, const void* indptr,
+                         int indptr_is_64, const int32_t* indices, const double* data, const int64_t* grid_index,
+                         int prune_zeros) {
+    // upload the hand-off
+    DevTemp d_ptr, d_idx, d_val;
+    const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
+    MG_TRY(d_ptr.alloc(ptr_bytes));
+    MG_TRY(d_idx.alloc((size_t)nnz * 4));
+    MG_TRY(d_val.alloc((size_t)nnz * 8));
+    HIP_TRY(hipMemcpyAsync(d_ptr.p, indptr, ptr_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_val.p, data, (size_t)nnz * 8, hipMemcpyHostToDevice, c->stream));
+    MG_TRY(upload_permutation(c, L, grid_index, n_rows));
     CsrArgs a{};
-    a.indptr = d_ptr; a.indptr64 = indptr_is_64; a.indices = d_idx; a.data = d_val; a.perm = L.perm;
-    a.n = n_rows; a.row0 = L.row0; a.nloc = L.nloc; a.lead = L.g.lead; a.xlen = L.xlen; a.prune = prune_zeros;
+    a.indptr = d_ptr.p; a.indptr64 = indptr_is_64; a.indices = static_cast<const int*>(d_idx.p); a.data = static_cast<const double*>(d_val.p);
+    a.perm = L.perm; a.n = n_rows; a.row0 = L.row0; a.nloc = L.nloc; a.lead = L.g.lead; a.xlen = L.xlen;
+    a.prune = prune_zeros;
+    // pass 1: widest kept row, kept entries, sanity flags
     unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->partials);
     HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(csr_scan, dim3(blocks_for(n_rows, 256)), dim3(256), 0, c->stream, a, d_stats);
     unsigned long long stats[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (stats[2] & 1ull) { cleanup(); return fail("a matrix row couples unknowns more than one grid plane apart (not a slab-local stencil)"); }
-    if ((stats[2] & 2ull) && c->require_diagonal) { cleanup(); return fail("a matrix row has a zero or missing diagonal"); }
+    if (stats[2] & 1ull)
+        return fail("a matrix row couples unknowns more than one grid plane apart (not a slab-local stencil)");
+    if ((stats[2] & 2ull) && c->require_diagonal) return fail("a matrix row has a zero or missing diagonal");
     L.W = (int)std::max<unsigned long long>(1, stats[0]);
     L.nnz_stored = stats[1];
-    if (int r = alloc_ell(c, L)) { cleanup(); return r; }
+    // pass 2: tiles
+    MG_TRY(alloc_ell(c, L));
     const dim3 g1(blocks_for(n_rows, 256)), b1(256);
     switch (L.R) {
         case 1: hipLaunchKernelGGL(csr_to_ell<1>, g1, b1, 0, c->stream, a, L.vals, L.cols, L.dinv, L.W); break;
@@ -1461,25 +1475,41 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
         default: hipLaunchKernelGGL(csr_to_ell<4>, g1, b1, 0, c->stream, a, L.vals, L.cols, L.dinv, L.W); break;
     }
     HIP_TRY(hipGetLastError());
-    // true non-zeros among the kept entries (== kept when pruned)
-    if (prune_zeros) {
-        L.nnz_nonzero = L.nnz_stored;
-    } else {
+    // true non-zeros among the kept entries (== kept when pruned); counted on the caller's copy (set-up only)
+    L.nnz_nonzero = L.nnz_stored;
+    if (!prune_zeros && (!c->comm.active() || L.replicated)) {
         unsigned long long nz = 0;
-        // count on the host copy the caller still owns (set-up only)
-        if (!c->comm.active() || L.replicated) {
-            for (int64_t q = 0; q < nnz; ++q) nz += data[q] != 0.0;
-        } else {
-            nz = L.nnz_stored;
-        }
+        for (int64_t q = 0; q < nnz; ++q) nz += data[q] != 0.0;
         L.nnz_nonzero = nz;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    cleanup();
     MG_TRY(encode_level(c, L));
     MG_TRY(repack_sdia(c, L, level));
     L.has_matrix = true;
     return finish_level(c, L);
+}
+
+}  // namespace
+
+int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                     const int32_t* indices, const double* data, const int64_t* grid_index, int prune_zeros) {
+    MG_TRY(check_level(c, level, false));
+    if (!indptr || !indices || !data) return fail("null CSR arrays");
+    if (n_rows <= 0 || nnz < 0) return fail("bad matrix dimensions");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, level, N, n_rows));
+    if (n_rows != L.n_global)
+        return fail("matrix has " + std::to_string(n_rows) + " rows, grid has " + std::to_string(L.n_global));
+    const int rc = build_level_from_csr(c, level, L, n_rows, nnz, indptr, indptr_is_64, indices, data, grid_index,
+                                        prune_zeros);
+    if (rc) {
+        const std::string why = g_err;
+        free_level(c, L);           // never leave a half-built level behind
+        g_err = why;
+    }
+    return rc;
 }
 
 int mg_set_level_grid(mg_handle c, int level, int N, int64_t n_rows, const int64_t* grid_index) {
@@ -1491,19 +1521,14 @@ int mg_set_level_grid(mg_handle c, int level, int N, int64_t n_rows, const int64
     MG_TRY(setup_geometry(c, level, N, n_rows));
     if (n_rows != L.n_global)
         return fail("vector has " + std::to_string(n_rows) + " entries, grid has " + std::to_string(L.n_global));
-    if (grid_index) {
-        std::vector<int> p32((size_t)n_rows);
-        std::vector<char> seen((size_t)n_rows, 0);
-        for (int64_t d = 0; d < n_rows; ++d) {
-            const int64_t p = grid_index[d];
-            if (p < 0 || p >= n_rows || seen[(size_t)p]) return fail("grid_index is not a permutation of the grid nodes");
-            seen[(size_t)p] = 1;
-            p32[(size_t)d] = (int)p;
-        }
-        MG_TRY(dev_alloc(c, &L.perm, (size_t)n_rows));
-        HIP_TRY(hipMemcpy(L.perm, p32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    int rc = upload_permutation(c, L, grid_index, n_rows);
+    if (!rc) rc = finish_level(c, L);
+    if (rc) {
+        const std::string why = g_err;
+        free_level(c, L);
+        g_err = why;
     }
-    return finish_level(c, L);
+    return rc;
 }
 
 int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {

@@ -165,24 +165,24 @@ typedef unsigned long long uvec4_t __attribute__((ext_vector_type(4)));
 // the re-used x lines from L2.
 template <int R, bool NT> __device__ __forceinline__ DVec<R> load_d(const double* p) {
     DVec<R> o;
-    if (!NT) return *reinterpret_cast<const DVec<R>*>(p);
-    if (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
-    else if (R == 2) { const dvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
+    if constexpr (!NT) return *reinterpret_cast<const DVec<R>*>(p);
+    else if constexpr (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
+    else if constexpr (R == 2) { const dvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
     else { const dvec4_t t = __builtin_nontemporal_load(reinterpret_cast<const dvec4_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; o.d[2 % R] = t.z; o.d[3 % R] = t.w; }
     return o;
 }
 template <int R, bool NT> __device__ __forceinline__ UVec<R> load_u(const unsigned long long* p) {
     UVec<R> o;
-    if (!NT) return *reinterpret_cast<const UVec<R>*>(p);
-    if (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
-    else if (R == 2) { const uvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const uvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
+    if constexpr (!NT) return *reinterpret_cast<const UVec<R>*>(p);
+    else if constexpr (R == 1) { o.d[0] = __builtin_nontemporal_load(p); }
+    else if constexpr (R == 2) { const uvec2_t t = __builtin_nontemporal_load(reinterpret_cast<const uvec2_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; }
     else { const uvec4_t t = __builtin_nontemporal_load(reinterpret_cast<const uvec4_t*>(p)); o.d[0] = t.x; o.d[1] = t.y; o.d[2 % R] = t.z; o.d[3 % R] = t.w; }
     return o;
 }
 template <int R, bool NT> __device__ __forceinline__ void store_d(double* p, const DVec<R>& v) {
-    if (!NT) { *reinterpret_cast<DVec<R>*>(p) = v; return; }
-    if (R == 1) { __builtin_nontemporal_store(v.d[0], p); }
-    else if (R == 2) { dvec2_t t; t.x = v.d[0]; t.y = v.d[1]; __builtin_nontemporal_store(t, reinterpret_cast<dvec2_t*>(p)); }
+    if constexpr (!NT) { *reinterpret_cast<DVec<R>*>(p) = v; }
+    else if constexpr (R == 1) { __builtin_nontemporal_store(v.d[0], p); }
+    else if constexpr (R == 2) { dvec2_t t; t.x = v.d[0]; t.y = v.d[1]; __builtin_nontemporal_store(t, reinterpret_cast<dvec2_t*>(p)); }
     else { dvec4_t t; t.x = v.d[0]; t.y = v.d[1]; t.z = v.d[2 % R]; t.w = v.d[3 % R]; __builtin_nontemporal_store(t, reinterpret_cast<dvec4_t*>(p)); }
 }
 
