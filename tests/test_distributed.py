@@ -22,10 +22,10 @@ def test_slab_splits_are_aligned_between_levels():
                     assert sf[r] <= 2 * K < sf[r + 1]              # coarse plane K lives with fine plane 2K
 
 
-@pytest.mark.parametrize("dim,lo,hi,c,rep", [(2, 1, 3, 8, 1000), (3, 1, 3, 2, 200)])
-def test_slab_decomposition_reproduces_serial_cpu(dim, lo, hi, c, rep):
+@pytest.mark.parametrize("world,dim,lo,hi,c,rep", [(2, 2, 1, 3, 8, 1000), (2, 3, 1, 3, 2, 200), (3, 2, 1, 3, 8, 1000)])
+def test_slab_decomposition_reproduces_serial_cpu(world, dim, lo, hi, c, rep):
     from tests.dist_workers import cpu_slab_worker
-    _spawn(cpu_slab_worker, 2, dim, lo, hi, c, 3, rep)
+    _spawn(cpu_slab_worker, world, dim, lo, hi, c, 3, rep)
 
 
 def test_bench_rendezvous_over_gloo():
@@ -34,11 +34,14 @@ def test_bench_rendezvous_over_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,lo,hi,c,rep,mode", [(2, 1, 3, 8, 1000, "csr"), (3, 1, 3, 2, 200, "gen"),
-                                                   (3, 1, 3, 4, 0, "gen")])
-def test_two_slabs_on_one_gpu_match_single_handle(dim, lo, hi, c, rep, mode):
+@pytest.mark.parametrize("world,dim,lo,hi,c,rep,mode", [(2, 2, 1, 3, 8, 1000, "csr"), (2, 3, 1, 3, 2, 200, "gen"),
+                                                         (2, 3, 1, 3, 4, 0, "gen"), (4, 3, 1, 3, 4, 0, "gen"),
+                                                         (3, 2, 1, 3, 8, 1000, "csr")])
+def test_slabs_on_one_gpu_match_single_handle(world, dim, lo, hi, c, rep, mode):
+    """2-4 processes share the GPU (interior ranks have two neighbours); results must equal the
+    single-handle run bit for bit."""
     from tests.dist_workers import gpu_slab_worker
-    _spawn(gpu_slab_worker, 2, dim, lo, hi, c, 2, rep, mode)
+    _spawn(gpu_slab_worker, world, dim, lo, hi, c, 2, rep, mode)
 
 
 @pytest.mark.gpu
