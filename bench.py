@@ -114,6 +114,10 @@ class Rendezvous:
 
 def build_hierarchy(args, rv):
     from multigrid_dolfinx_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):          # a checkout without the (git-ignored) build product
+        if rv.rank == 0:
+            _capi.build_extension()
+        rv.barrier()
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     import ctypes as C
     dim, lo, hi, _ = CONFIGS[args.config]

@@ -74,6 +74,12 @@ class MgError(RuntimeError):
     """A non-zero status from libmg_hip.so; the message is mg_last_error()."""
 
 
+def build_extension():
+    """Compile libmg_hip.so in-tree with hipcc (gfx950).  Building is not a fallback: nothing runs without it."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=True)
+
+
 def load():
     """Load libmg_hip.so and declare every prototype of include/mg_hip.h."""
     global _lib

@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_extension():
+    """The HIP extension is built in-tree by `__graft_entry__.build()`; if a checkout arrives without the
+    (git-ignored) shared library, build it once before the tests that need it."""
+    from multigrid_dolfinx_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        try:
+            _capi.build_extension()
+        except Exception as exc:                     # pragma: no cover - reported by the tests that load it
+            print(f"could not build libmg_hip.so: {exc}")
+    yield
