@@ -851,6 +851,37 @@ int build_direct(mg_context* c) {
     return rc;
 }
 
+int direct_solve(mg_context* c);
+
+// The factorisation uses no pivoting, which is safe for the SPD / M-matrices this path is meant for but not
+// for an arbitrary hand-off: solve once against a known right-hand side (all ones) and keep the direct
+// solver only if the residual is at round-off; otherwise the coarsest level falls back to PCG.
+int validate_direct(mg_context* c) {
+    DirectSolver& d = c->direct;
+    if (!d.ok) return 0;
+    Level& L = c->L[0];
+    double* saved = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&saved), (size_t)L.xlen * 8));
+    int rc = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(saved, L.f.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+        std::vector<double> ones((size_t)L.nloc, 1.0);
+        HIP_TRY(hipMemcpyAsync(L.f.rows, ones.data(), (size_t)L.nloc * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        MG_TRY(direct_solve(c));
+        MG_TRY(launch_ell(c, L, MODE_RESIDUAL, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
+        double rn = 0.0;
+        MG_TRY(norm2(c, L, L.v2.rows, &rn));
+        const double rel = rn / std::sqrt((double)L.nloc);
+        if (!(rel <= 1e-9)) d.ok = false;           // also catches NaN
+        HIP_TRY(hipMemcpyAsync(L.f.base, saved, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    (void)hipFree(saved);
+    if (rc || !d.ok) { free_direct(c); d.tried = true; }
+    return rc;
+}
+
 int direct_solve(mg_context* c) {
     DirectSolver& d = c->direct;
     Level& L = c->L[0];
@@ -877,7 +908,7 @@ int pcg_solve(mg_context* c, int* iters_out, double* rel_out);
 // Coarsest level: v = A^-1 f, standing in for the reference's exact spsolve (multigrid.py:239-241):
 // the block-tridiagonal LU where the level allows it, otherwise Jacobi-preconditioned CG.
 int coarse_solve(mg_context* c, int* iters_out, double* rel_out) {
-    if (!c->direct.tried) MG_TRY(build_direct(c));
+    if (!c->direct.tried) { MG_TRY(build_direct(c)); MG_TRY(validate_direct(c)); }
     if (c->direct.ok) {
         if (iters_out) *iters_out = 0;
         if (rel_out) *rel_out = 0.0;
@@ -974,7 +1005,7 @@ void drop_graphs(mg_context* c) {
 // MG_VEC_V buffers mu1+mu2 times per level; the captured pointer state is part of the cache key and the
 // swaps are re-applied on the host after a replay.
 int vcycle_graphed(mg_context* c, int level) {
-    if (!c->direct.tried) MG_TRY(build_direct(c));
+    if (!c->direct.tried) { MG_TRY(build_direct(c)); MG_TRY(validate_direct(c)); }
     if (!c->use_graph || c->comm.active() || level == 0 || !c->direct.ok) return vcycle(c, level);
     if (c->keep_err)
         for (int l = 1; l <= level; ++l) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].err));

@@ -595,3 +595,27 @@ def test_graph_replay_equals_eager_launches(mu):
             outs.append((dev.get_vector(3, "v"), np.array(res), dev.get_vector(3, "err"), dev.get_vector(2, "f")))
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_direct_solver_rejects_matrices_it_cannot_factor():
+    """No pivoting: a coarsest matrix with a vanishing leading pivot block must fall back to PCG (or fail
+    loudly), never return garbage."""
+    import scipy.sparse as sps
+    from multigrid_dolfinx_amd._capi import MgError
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    lvl = poisson.make_level(16, 2)
+    A = lvl.A.tolil()
+    interior = int(np.flatnonzero(np.abs(lvl.A.diagonal() - 4.0) < 1e-12)[0])
+    A[interior, interior] = 1e-300                                  # breaks the pivot-free elimination
+    A = sps.csr_matrix(A)
+    with DeviceHierarchy(2, 0, 0, c=16) as dev:
+        dev.set_level(0, A, lvl.grid_index)
+        dev.set_params(1, 1, 2 / 3, coarse_maxit=50)
+        dev.set_vector(0, "f", lvl.b)
+        try:
+            its, rel = dev.coarse_solve()
+            assert its > 0                                          # PCG took over
+            r = lvl.b - A.dot(dev.get_vector(0, "v"))
+            assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(lvl.b)
+        except MgError as exc:
+            assert "did not converge" in str(exc)
