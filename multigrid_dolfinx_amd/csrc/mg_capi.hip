@@ -1880,7 +1880,7 @@ int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* re
         MG_TRY(exchange_halo(c, L, L.v));
         if (l < top || tol <= 0.0) {
             for (int k = 0; k < mu0; ++k) {
-                MG_TRY(vcycle(c, l));
+                MG_TRY(vcycle_graphed(c, l));
                 if (l == top) {
                     ++done_cycles;
                     if (resid_l2) {
@@ -1891,7 +1891,7 @@ int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* re
             }
         } else {
             for (int k = 0; k < max_cycles; ++k) {
-                MG_TRY(vcycle(c, l));
+                MG_TRY(vcycle_graphed(c, l));
                 ++done_cycles;
                 MG_TRY(residual(c, l));
                 double rn = 0.0;
