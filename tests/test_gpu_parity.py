@@ -619,3 +619,22 @@ def test_direct_solver_rejects_matrices_it_cannot_factor():
             assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(lvl.b)
         except MgError as exc:
             assert "did not converge" in str(exc)
+
+
+def test_3d_n128_reference_parameters_match_oracle():
+    """The largest 3-D oracle comparison that fits a test budget: 129^3 unknowns, 3 levels (coarsest 33^3 =
+    BASELINE's coarsest grid), the reference's V(50,50), omega = 2/3.  3-D is parity-unpinned (no reference);
+    this pins the HIP path to the CPU restatement at the north-star tolerance."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle
+    bag = poisson.make_hierarchy(3, 2, 4, c=8, mu1=50, mu2=50)
+    orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=3)
+    f = bag.b_dict[4]
+    want = orc.v_cycle(orc.A_jacobi_sp_dict[4], np.zeros_like(f), f)
+    r = f - bag.A_sp_dict[4][0].dot(want)
+    with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=50, mu2=50) as dev:
+        dev.zero_vector(4, "v")
+        res = dev.vcycle(4, 1, residuals=True)
+        got = dev.get_vector(4, "v")
+    assert rel_l2(got, want) <= TOL_ITER
+    assert abs(res[0] - np.linalg.norm(r)) <= TOL_ITER * np.linalg.norm(r)
