@@ -638,3 +638,21 @@ def test_3d_n128_reference_parameters_match_oracle():
         got = dev.get_vector(4, "v")
     assert rel_l2(got, want) <= TOL_ITER
     assert abs(res[0] - np.linalg.norm(r)) <= TOL_ITER * np.linalg.norm(r)
+
+
+@pytest.mark.parametrize("dim,c,seed", [(2, 5, None), (2, 7, 3), (3, 3, None), (3, 5, 8), (2, 1, None), (3, 1, 2)])
+def test_unusual_grid_sizes_match_oracle(dim, c, seed):
+    """Coarsest grids that are not powers of two (odd node counts per axis, tiny grids with c = 1): the
+    slice / strip / lead-region arithmetic must not depend on friendly sizes."""
+    bag, orc, dev = _oracle_and_device(dim, 1, 3, c, seed, 3)
+    with dev:
+        f = bag.b_dict[3]
+        want = orc.v_cycle(orc.A_jacobi_sp_dict[3], np.zeros_like(f), f)
+        got = _one_cycle(dev, 3, f)
+        assert rel_l2(got, want) <= TOL_ITER
+        t = orc.full_multigrid_test(orc.A_jacobi_sp_dict[3], f, True)
+        for l in (1, 2):
+            dev.set_rhs_true(l, bag.b_dict[l])
+        dev.set_vector(3, "f", f)
+        dev.fmg(2)
+        assert rel_l2(dev.get_vector(3, "v"), t[0]) <= TOL_ITER
