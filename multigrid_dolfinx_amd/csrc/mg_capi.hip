@@ -462,7 +462,6 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
                int64_t slice0 = 0, int64_t slice_count = -1, int color = 0) {
     if (slice_count < 0) slice_count = L.nslices - slice0;
     if (slice_count == 0) return 0;
-    const bool whole = slice0 == 0 && slice_count == L.nslices;
     EllArgs a{};
     a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
@@ -474,10 +473,12 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     auto plan_strips = [&]() {
         const int64_t ps4 = (L.g.plane / (WAVE * L.R)) / 4;            // blocks per pseudo-plane
         const int64_t want = c->strip_slices / 4;                       // blocks per strip asked for
-        if (!(whole && want > 0 && !dot && L.g.nz > 1 && ps4 >= 16 * want)) return;
+        // (sub-ranges of a slab -- interior slices while the halo travels -- are strip-walked too: the
+        // pseudo-planes then start at slice0, which shifts them against the real planes by a constant)
+        const int64_t nblocks = (slice_count + 3) / 4;
+        if (!(want > 0 && !dot && L.g.nz > 1 && ps4 >= 16 * want && nblocks >= 4 * ps4)) return;
         const int64_t m = std::max<int64_t>(1, (ps4 + 4 * want) / (8 * want));     // round(ps4 / want / 8)
         const int64_t ns = 8 * m;
-        const int64_t nblocks = (L.nslices + 3) / 4;
         const int64_t kp = (nblocks + ps4 - 1) / ps4;
         const int64_t bmax = (ps4 + ns - 1) / ns;
         const int64_t g = ns * kp * bmax;

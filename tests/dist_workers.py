@@ -56,7 +56,7 @@ def rendezvous_worker(rank, world, port):
         rv.close()
 
 
-def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode):
+def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode, tuning=None):
     """world processes share GPU 0; slabs talk through the host-staged callback transport over gloo.
     Checks the distributed HIP path against a single-handle run on the same GPU."""
     from multigrid_dolfinx_amd import poisson
@@ -72,13 +72,14 @@ def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode
         bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=mu, mu2=mu, seed=None if mode == "gen" else 3)
         gi = {l: L.grid_index for l, L in bag.levels.items()}
         f = bag.b_dict[hi]
+        tuning = tuning or {}
         if mode == "gen":
-            par = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm)
-            ser = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu)
+            par = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, **tuning)
+            ser = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, **tuning)
         else:
-            par = DeviceHierarchy(dim, lo, hi, c=c)
+            par = DeviceHierarchy(dim, lo, hi, c=c, **tuning)
             comm(par)
-            ser = DeviceHierarchy(dim, lo, hi, c=c)
+            ser = DeviceHierarchy(dim, lo, hi, c=c, **tuning)
             for h in (par, ser):
                 for l in range(lo, hi + 1):
                     h.set_level(l, bag.A_sp_dict[l][0], gi[l])

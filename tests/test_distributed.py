@@ -45,6 +45,14 @@ def test_slabs_on_one_gpu_match_single_handle(world, dim, lo, hi, c, rep, mode):
 
 
 @pytest.mark.gpu
+def test_slab_interior_is_strip_walked_while_the_halo_travels():
+    """129^3 unknowns on two slabs with 8-slice strips: the interior sub-range of every sweep uses the XCD
+    strip traversal (a different slice order), the boundary slices the chunked map."""
+    from tests.dist_workers import gpu_slab_worker
+    _spawn(gpu_slab_worker, 2, 3, 2, 4, 8, 2, 0, "gen", {"strip_slices": 8})
+
+
+@pytest.mark.gpu
 def test_rccl_entry_points_on_one_rank():
     """Every RCCL call the slab transport makes (unique id by value, init, all-reduce, grouped
     broadcast, grouped send/recv, destroy), on a one-rank communicator -- all a 1-GPU box can run."""
