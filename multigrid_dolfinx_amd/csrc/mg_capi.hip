@@ -412,8 +412,10 @@ void launch_ell_coded_wr(int mode, bool dot, bool nt, const EllArgs& a, unsigned
 }
 
 template <int WU, int R, bool NT>
-void launch_sdia_wrn(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s) {
-    if (mode == MODE_RESIDUAL)
+void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (mode == MODE_JACOBI && finest)
+        hipLaunchKernelGGL((sdia_jacobi_finest<WU, R, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_RESIDUAL)
         hipLaunchKernelGGL((sdia_apply<WU, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_JACOBI)
         hipLaunchKernelGGL((sdia_apply<WU, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
@@ -426,11 +428,11 @@ void launch_sdia_wrn(int mode, bool dot, const EllArgs& a, unsigned grid, hipStr
 }
 
 template <int R>
-void launch_sdia_r(int WU, int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s) {
+void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
     switch (WU) {
-        case 3: nt ? launch_sdia_wrn<3, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<3, R, false>(mode, dot, a, grid, s); break;
-        case 4: nt ? launch_sdia_wrn<4, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<4, R, false>(mode, dot, a, grid, s); break;
-        default: nt ? launch_sdia_wrn<8, R, true>(mode, dot, a, grid, s) : launch_sdia_wrn<8, R, false>(mode, dot, a, grid, s); break;
+        case 3: nt ? launch_sdia_wrn<3, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<3, R, false>(mode, dot, finest, a, grid, s); break;
+        case 4: nt ? launch_sdia_wrn<4, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<4, R, false>(mode, dot, finest, a, grid, s); break;
+        default: nt ? launch_sdia_wrn<8, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<8, R, false>(mode, dot, finest, a, grid, s); break;
     }
 }
 
@@ -493,10 +495,11 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         plan_strips();
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
+        const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
         switch (L.R) {
-            case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, a, grid, c->stream); break;
-            case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, a, grid, c->stream); break;
-            case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, a, grid, c->stream); break;
+            case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
+            case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
+            case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
             default: return fail("unsupported rows_per_lane");
         }
         HIP_TRY(hipGetLastError());
