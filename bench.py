@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--graph", type=int, default=None, help="0 = launch every kernel of a V-cycle eagerly")
     ap.add_argument("--replicate-below", type=int, default=1 << 22,
                     help="levels with fewer unknowns are replicated on every rank")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
+                    help="slab transport for N > 1: RCCL over xGMI (default) or host-staged gloo callbacks "
+                         "(debugging on a box with fewer GPUs than ranks; slow, never a headline number)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-level", type=int, default=4, help="finest level of the CPU sample (N = 8*2^l)")
@@ -112,6 +115,41 @@ class Rendezvous:
             self.dist.destroy_process_group()
 
 
+class GlooCallbacks:
+    """Host-staged slab transport over gloo (mg_set_comm_callbacks); debugging only."""
+
+    def __init__(self, rv):
+        self.rv, self.dist = rv, rv.dist
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        import torch
+        reqs = []
+        if recv_lo is not None:
+            reqs.append(self.dist.irecv(torch.from_numpy(recv_lo), src=self.rv.rank - 1))
+        if recv_hi is not None:
+            reqs.append(self.dist.irecv(torch.from_numpy(recv_hi), src=self.rv.rank + 1))
+        if send_lo is not None:
+            reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(send_lo)), dst=self.rv.rank - 1))
+        if send_hi is not None:
+            reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(send_hi)), dst=self.rv.rank + 1))
+        for r in reqs:
+            r.wait()
+
+    def allreduce(self, buf):
+        import torch
+        self.dist.all_reduce(torch.from_numpy(buf))
+
+    def allgatherv(self, send, recv, counts):
+        import torch
+        off = 0
+        for r in range(self.rv.world):
+            seg = recv[off:off + int(counts[r])]
+            if r == self.rv.rank:
+                seg[:] = send
+            self.dist.broadcast(torch.from_numpy(seg), src=r)
+            off += int(counts[r])
+
+
 def build_hierarchy(args, rv):
     from multigrid_dolfinx_amd import _capi
     if not os.path.exists(_capi.LIB_PATH):          # a checkout without the (git-ignored) build product
@@ -139,8 +177,25 @@ def build_hierarchy(args, rv):
     if args.graph is not None:
         tuning["graph"] = args.graph
 
+    if rv.world > 1 and args.transport == "rccl":
+        # every rank must be able to load RCCL before anybody enters the collective communicator set-up;
+        # if one cannot, ALL ranks switch to the host-staged transport (reported in config.parallelism)
+        ok = 1.0
+        try:
+            _capi.check(_capi.load().mg_comm_unique_id(C.create_string_buffer(128), 128))
+        except Exception as exc:            # noqa: BLE001 - any failure means "no RCCL here"
+            print(f"rank {rv.rank}: RCCL unavailable ({exc}); falling back to gloo host staging", file=sys.stderr)
+            ok = 0.0
+        if rv.max(1.0 - ok) > 0.0:
+            args.transport = "gloo"
+
     def comm(h):
         if rv.world == 1:
+            return
+        if args.transport == "gloo":
+            t = GlooCallbacks(rv)
+            h.set_comm_callbacks(rv.rank, rv.world, t.exchange, t.allreduce, t.allgatherv,
+                                 replicate_below=args.replicate_below)
             return
         uid = None
         if rv.rank == 0:
@@ -150,8 +205,12 @@ def build_hierarchy(args, rv):
         uid = rv.broadcast_bytes(uid)
         h.set_comm_rccl(rv.rank, rv.world, uid, replicate_below=args.replicate_below)
 
+    device = rv.local_rank
+    if args.transport == "gloo":            # ranks may share a GPU in this debugging mode
+        import torch
+        device = rv.local_rank % max(1, torch.cuda.device_count())
     return DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega,
-                                     prune_zeros=True, device=rv.local_rank, comm=comm, **tuning)
+                                     prune_zeros=True, device=device, comm=comm, **tuning)
 
 
 def timed_cycles(h, rv, level, warmup, steps):
@@ -252,7 +311,8 @@ def main():
                                    f"explicit zeros pruned (7-point rows)" if dim == 3 else
                                    f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi",
                        "levels": hi - lo + 1, "dim": dim, "elements_per_dim": 8 * 2 ** hi,
-                       "parallelism": f"slab{args.gpus}" if args.gpus > 1 else "single"},
+                       "parallelism": (f"slab{args.gpus}" + ("-gloo-host-staged" if args.transport == "gloo" else ""))
+                                      if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("sdia_apply" if info["symmetric_diagonals"] else
