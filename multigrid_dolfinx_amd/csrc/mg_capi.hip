@@ -1271,6 +1271,7 @@ int mg_destroy(mg_handle c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     drop_graphs(c);
     for (auto& L : c->L) free_level(c, L);
     (void)hipFree(c->partials);
