@@ -322,6 +322,10 @@ def main():
                                      "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
                          "kernel_ms": jac_ms, "algorithmic_bytes_per_launch": bytes_jacobi,
                          "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
+                         # what the kernel really moves (PMC, profiles/traffic.json) per second: the shipped
+                         # formats move fewer bytes than the algorithmic count, hence frac can exceed 1
+                         "traffic_GBs": (traffic / (jac_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "residual_kernel_ms": res_ms,
                          "residual_achieved_GBs": bytes_resid / (res_ms * 1e-3) / 1e9},
             "v22_cycles_per_s": v22_per_s, "residual_l2_after": res_after, "rhs_l2": f_norm,
