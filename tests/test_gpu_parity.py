@@ -656,3 +656,36 @@ def test_unusual_grid_sizes_match_oracle(dim, c, seed):
         dev.set_vector(3, "f", f)
         dev.fmg(2)
         assert rel_l2(dev.get_vector(3, "v"), t[0]) <= TOL_ITER
+
+
+def test_mass_matrix_norm_and_error_calculators(mg):
+    """`res_calculator` / `err_calculator` (multigrid.py:203-218) assemble sqrt(int r^2) with dolfinx; here the
+    caller passes the P1 mass matrix M and the device evaluates sqrt(r^T M r) (SpMV fused with the dot)."""
+    import scipy.sparse as sps
+    N = 24
+    n1 = N + 1
+    h = 1.0 / N
+    # P1 mass matrix of the right-diagonal unit-square mesh: h^2/12 * (6 on the diagonal, 1 per edge), halved /
+    # quartered weights on the boundary follow from summing element contributions
+    idx = np.arange(n1 * n1).reshape(n1, n1)
+    rows, cols, vals = [], [], []
+    loc = (h * h / 24.0) * (np.ones((3, 3)) + np.eye(3))
+    for j in range(N):
+        for i in range(N):
+            for tri in ((idx[j, i], idx[j, i + 1], idx[j + 1, i + 1]), (idx[j, i], idx[j + 1, i + 1], idx[j + 1, i])):
+                for a in range(3):
+                    for b in range(3):
+                        rows.append(tri[a]); cols.append(tri[b]); vals.append(loc[a, b])
+    M = sps.csr_matrix((vals, (rows, cols)), shape=(n1 * n1, n1 * n1))
+    M.sum_duplicates()
+    rng = np.random.default_rng(4)
+    r = rng.standard_normal((n1 * n1, 1))
+    u = rng.standard_normal((n1 * n1, 1))
+    want = float(np.sqrt((r.T @ (M @ r)).item()))
+    assert abs(mg.res_calculator(r, M) - want) <= 1e-13 * want
+    assert abs(mg.res_calculator(r, None) - np.linalg.norm(r)) <= 1e-13 * np.linalg.norm(r)
+    d = u - r
+    want = float(np.sqrt((d.T @ (M @ d)).item()))
+    assert abs(mg.err_calculator(u, r, M) - want) <= 1e-13 * want
+    ones = np.ones((n1 * n1, 1))
+    assert abs(mg.res_calculator(ones, M) - 1.0) <= 1e-13          # sqrt(area of the unit square)
