@@ -741,7 +741,9 @@ int prolong(mg_context* c, int level, int add) {
     Level& C = c->L[level - 1];
     const bool keep = !add || c->keep_err;
     if (keep) MG_TRY(vec_alloc(c, F, &F.err));
-    const dim3 grid = grid3(F.g, F.g.nk);
+    // one thread per pair of fine nodes along x
+    const int64_t pairs = (int64_t)((F.g.nx + 1) / 2) * F.g.ny;
+    const dim3 grid((unsigned)((pairs + kPlaneBlock - 1) / kPlaneBlock), (unsigned)F.g.nk, 1u);
     if (add && keep)
         hipLaunchKernelGGL((prolong_correct<true, true>), grid, dim3(kPlaneBlock), 0, c->stream, C.g, F.g, C.v.base, F.v.base, F.err.base);
     else if (add)

@@ -901,32 +901,42 @@ __global__ void restrict_full_weighting(Grid gc, Grid gf, const double* __restri
 // Q1 prolongation + correction (Interpolation2D, multigrid.py:59-120, and `v_h + err_h`, :260):
 // coincident nodes copy, edge nodes 0.5*(a+b), face/cell centres 0.25*(..)/0.125*(..), summed
 // x-neighbour first as the reference does.  err (optional) receives the interpolated values.
+// One thread handles the fine nodes (2p, 2p+1) of a line: they share their coarse neighbours, and the
+// parity along x -- the only one that differs between adjacent lanes -- no longer diverges.
 template <bool ADD, bool KEEP>
 __global__ void prolong_correct(Grid gc, Grid gf, const double* __restrict__ vc, double* __restrict__ vf,
                                 double* __restrict__ err) {
-    int i, j;
-    if (!plane_node(gf, &i, &j)) return;
+    const unsigned ppl = (unsigned)(gf.nx + 1) / 2u;                 // pairs per line
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ppl * (unsigned)gf.ny) return;
+    const int j = (int)(t / ppl);
+    const int p = (int)(t - (unsigned)j * ppl);
     const int kl = blockIdx.y;
     const int k = gf.k0 + kl;
-    const int pi = i & 1, pk = k & 1;
+    const int pk = k & 1;
     const int pj = gf.refine_y ? (j & 1) : 0;
-    const int ic = i >> 1, kc = (k >> 1) - gc.k0;
+    const int kc = (k >> 1) - gc.k0;
     const int jc = gf.refine_y ? (j >> 1) : j;
-    const double* base = vc + gc.lead + (int64_t)kc * gc.plane + (int64_t)jc * gc.nx + ic;
-    double s = 0.0;
+    const bool has_odd = 2 * p + 1 < gf.nx;                          // the last pair of an odd line is a single node
+    const double* base = vc + gc.lead + (int64_t)kc * gc.plane + (int64_t)jc * gc.nx + p;
+    double s0 = 0.0, s1 = 0.0;
     bool first = true;
     for (int dk = 0; dk <= pk; ++dk)
-        for (int dj = 0; dj <= pj; ++dj)
-            for (int di = 0; di <= pi; ++di) {
-                const double c = base[(int64_t)dk * gc.plane + (int64_t)dj * gc.nx + di];
-                s = first ? c : s + c;
-                first = false;
-            }
-    const int cnt = 1 << (pi + pj + pk);
-    const double e = cnt == 1 ? s : (1.0 / (double)cnt) * s;
-    const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + i;
-    if (KEEP) err[o] = e;
-    if (ADD) vf[o] = vf[o] + e;
+        for (int dj = 0; dj <= pj; ++dj) {
+            const double* q = base + (int64_t)dk * gc.plane + (int64_t)dj * gc.nx;
+            const double a = q[0];
+            const double b = has_odd ? q[1] : 0.0;
+            s0 = first ? a : s0 + a;                                 // even node: (dk, dj) corners
+            s1 = first ? a : s1 + a;                                 // odd node: x-neighbour first, as the reference
+            s1 = s1 + b;
+            first = false;
+        }
+    const int c0 = 1 << (pj + pk);
+    const double e0 = c0 == 1 ? s0 : (1.0 / (double)c0) * s0;
+    const double e1 = (1.0 / (double)(2 * c0)) * s1;
+    const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + 2 * p;
+    if (KEEP) { err[o] = e0; if (has_odd) err[o + 1] = e1; }
+    if (ADD) { vf[o] = vf[o] + e0; if (has_odd) vf[o + 1] = vf[o + 1] + e1; }
 }
 
 // ---- vector utilities ---------------------------------------------------------------------------
