@@ -12,6 +12,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,7 +68,14 @@ RcclApi g_rccl;
 
 int load_rccl() {
     if (g_rccl.lib) return 0;
-    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // MG_RCCL_LIBRARY: load another implementation of the same ten entry points (tests use an in-process
+    // stand-in to exercise the asynchronous stream / event ordering of the slab transport on one GPU)
+    void* lib = nullptr;
+    if (const char* override_path = getenv("MG_RCCL_LIBRARY")) {
+        lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return fail(std::string("cannot load MG_RCCL_LIBRARY: ") + dlerror());
+    }
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return fail(std::string("cannot load librccl: ") + dlerror());
 #define SYM(field, name)                                                      \

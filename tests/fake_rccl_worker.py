@@ -1,0 +1,86 @@
+"""Runs in its own process with MG_RCCL_LIBRARY pointing at tests/fake_rccl/libfake_rccl.so: `world` threads
+play the ranks of the slab decomposition on one GPU, going through the library's real RCCL code path
+(mg_set_comm, grouped ncclSend/ncclRecv on the communication stream, all-reduce, grouped broadcasts) with
+asynchronous, event-ordered copies -- unlike the host-staged callback transport, which synchronises every
+exchange.  Results must equal a single-handle run bit for bit."""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from multigrid_dolfinx_amd import _capi                              # noqa: E402
+from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy          # noqa: E402
+
+
+def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
+    assert "fake_rccl" in os.environ.get("MG_RCCL_LIBRARY", "")
+    buf = C.create_string_buffer(128)
+    _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
+    uid = buf.raw
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            def comm(h):
+                h.set_tuning("overlap", overlap)
+                h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
+            h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm)
+            info = h.level_info(hi)
+            assert not info["replicated"] and info["n_local"] < info["n_global"]
+            h.zero_vector(hi, "v")
+            res = h.vcycle(hi, 3, residuals=True)
+            full = h.get_vector(hi, "v", gather=True)
+            h.set_params(mu, mu, 2 / 3, restriction="full_weighting")
+            h.zero_vector(hi, "v")
+            h.vcycle(hi, 1)
+            fw = h.get_vector(hi, "v", gather=True)
+            h.set_params(mu, mu, 1.0, smoother="rbgs")
+            h.zero_vector(hi, "v")
+            h.vcycle(hi, 1)
+            gs = h.get_vector(hi, "v", gather=True)
+            nrm = h.norm2(hi, "v")
+            results[rank] = (full, res, fw, gs, nrm)
+            h.close()
+        except Exception as exc:                                     # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            errors.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
+    assert not errors, errors
+
+    with DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu) as ser:
+        ser.zero_vector(hi, "v")
+        res = ser.vcycle(hi, 3, residuals=True)
+        want = ser.get_vector(hi, "v")
+        ser.set_params(mu, mu, 2 / 3, restriction="full_weighting")
+        ser.zero_vector(hi, "v")
+        ser.vcycle(hi, 1)
+        want_fw = ser.get_vector(hi, "v")
+        ser.set_params(mu, mu, 1.0, smoother="rbgs")
+        ser.zero_vector(hi, "v")
+        ser.vcycle(hi, 1)
+        want_gs = ser.get_vector(hi, "v")
+        want_nrm = ser.norm2(hi, "v")
+    for rank in range(world):
+        full, r, fw, gs, nrm = results[rank]
+        assert np.array_equal(full, want), (rank, float(np.abs(full - want).max()))
+        assert np.all(np.abs(r - res) <= 1e-13 * res)
+        assert np.array_equal(fw, want_fw) and np.array_equal(gs, want_gs)
+        assert abs(nrm - want_nrm) <= 1e-13 * want_nrm
+    print(f"fake-rccl world={world} dim={dim} overlap={overlap}: OK")
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:9]]
+    main(*a)

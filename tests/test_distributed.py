@@ -58,3 +58,26 @@ def test_rccl_entry_points_on_one_rank():
     broadcast, grouped send/recv, destroy), on a one-rank communicator -- all a 1-GPU box can run."""
     from multigrid_dolfinx_amd import _capi
     _capi.check(_capi.load().mg_comm_selftest(0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap", [(2, 3, 1, 3, 4, 0, 1), (4, 3, 1, 3, 4, 0, 1), (3, 2, 1, 3, 8, 1000, 1),
+                                                         (4, 3, 1, 3, 4, 0, 0), (2, 3, 2, 4, 8, 300000, 1)])
+def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi, c, rep, overlap):
+    """The library's RCCL branch (not the callback transport): grouped send/recv on the communication stream,
+    ordered by events against the boundary / interior sweeps, all-reduce, grouped broadcasts -- executed against
+    an in-process stand-in for librccl (tests/fake_rccl) with one thread per rank on one GPU.  A real multi-GPU
+    RCCL run is not possible on the builder's box; this pins the call pattern and the stream ordering."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
+    env = dict(os.environ, MG_RCCL_LIBRARY=lib)
+    out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), str(dim), str(lo),
+                          str(hi), str(c), "2", str(rep), str(overlap)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "OK" in out.stdout
