@@ -254,3 +254,99 @@ def make_hierarchy(dim: int, coarsest_level: int, finest_level: int, c: int = 8,
                      coarsest_level=coarsest_level, finest_level=finest_level, A_sp_dict=As,
                      A_jacobi_sp_dict={}, b_dict=bs, mu0=mu0, mu1=mu1, mu2=mu2, omega=omega,
                      levels=levels, dim=dim)
+
+
+# ---- P2 elements (BASELINE.json config 5; no reference implementation exists) ---------------------------------
+def _p2_local_stiffness(verts: np.ndarray) -> np.ndarray:
+    """Stiffness of one P2 simplex (triangle: 6 nodes, tetrahedron: 10 nodes) with vertex coordinates
+    `verts` ((d+1, d)); node order: vertices, then edge midpoints (a, b) for a < b."""
+    d = verts.shape[1]
+    nv = d + 1
+    T = np.hstack([np.ones((nv, 1)), verts])
+    grad_lam = np.linalg.inv(T)[1:, :].T                 # (nv, d): gradient of each barycentric coordinate
+    vol = abs(np.linalg.det(T)) / (2.0 if d == 2 else 6.0)
+    edges = [(a, b) for a in range(nv) for b in range(a + 1, nv)]
+    # degree-2 quadrature: triangle -> edge midpoints (weights 1/3); tetrahedron -> 4-point rule
+    if d == 2:
+        pts = np.array([[0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]])
+        wts = np.full(3, 1.0 / 3.0)
+    else:
+        a, b = 0.5854101966249685, 0.1381966011250105
+        pts = np.full((4, 4), b) + (a - b) * np.eye(4)
+        wts = np.full(4, 0.25)
+    nn = nv + len(edges)
+    K = np.zeros((nn, nn))
+    for lam, w in zip(pts, wts):
+        G = np.zeros((nn, d))
+        for i in range(nv):
+            G[i] = (4.0 * lam[i] - 1.0) * grad_lam[i]
+        for e, (i, j) in enumerate(edges):
+            G[nv + e] = 4.0 * (lam[i] * grad_lam[j] + lam[j] * grad_lam[i])
+        K += w * vol * (G @ G.T)
+    return K
+
+
+def p2_level(N: int, dim: int, seed: Optional[int] = None) -> Level:
+    """P2 Poisson level on the structured simplicial mesh with N cells per dimension: the DoFs are ALL points
+    of the (2N+1)^dim lattice (vertices, edge / face-diagonal / body-diagonal midpoints), so `Level.N` is 2N and
+    the lattice nests under refinement like the P1 grids do.  Same problem, boundary treatment and hand-off
+    conventions as `lexicographic_level`; the stencil reaches two lattice planes.  Because P2 reproduces the
+    quadratic manufactured solution exactly, the discrete solution equals the nodal exact values."""
+    M = 2 * N
+    n1 = M + 1
+    n = n1 ** dim
+    h = 1.0 / N
+    idx = np.arange(n, dtype=np.int64)
+    ijk = [idx % n1, (idx // n1) % n1] + ([idx // (n1 * n1)] if dim == 3 else [])
+    coords = np.zeros((n, 3))
+    for d in range(dim):
+        coords[:, d] = ijk[d] / M
+    on_bnd = np.zeros(n, dtype=bool)
+    for cdir in ijk:
+        on_bnd |= (cdir == 0) | (cdir == M)
+    g = boundary_data(coords, dim)
+    # reference simplices of one cell (right diagonal in 2-D, Kuhn split in 3-D), vertex offsets in cells
+    import itertools
+    simplices = []
+    for perm in itertools.permutations(range(dim)):
+        v = [np.zeros(dim, dtype=int)]
+        for ax in perm:
+            nxt = v[-1].copy()
+            nxt[ax] += 1
+            v.append(nxt)
+        simplices.append(np.array(v))
+    strides = np.array([1, n1, n1 * n1][:dim])
+    cells = np.stack(np.meshgrid(*[np.arange(N)] * dim, indexing="ij"), axis=-1).reshape(-1, dim)
+    rows, cols, vals = [], [], []
+    load = np.zeros(n)
+    f = source_term(dim)
+    for sv in simplices:
+        K = _p2_local_stiffness(sv * h)
+        nv = dim + 1
+        edges = [(a, b) for a in range(nv) for b in range(a + 1, nv)]
+        local = [2 * sv[a] for a in range(nv)] + [sv[a] + sv[b] for a, b in edges]       # lattice offsets
+        node = np.stack([(2 * cells + off) @ strides for off in local], axis=1)           # (ncells, nn)
+        nn = node.shape[1]
+        rows.append(np.repeat(node, nn, axis=1).reshape(-1))
+        cols.append(np.tile(node, (1, nn)).reshape(-1))
+        vals.append(np.tile(K.reshape(-1), cells.shape[0]))
+        # load vector of a constant source: vertices get 0 (2-D) / -vol/20 (3-D), edge nodes vol/3 / vol/5
+        vol = h ** dim / (2.0 if dim == 2 else 6.0)
+        wv, we = (0.0, vol / 3.0) if dim == 2 else (-vol / 20.0, vol / 5.0)
+        for a in range(nn):
+            np.add.at(load, node[:, a], f * (wv if a < nv else we))
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    # symmetric Dirichlet treatment with explicit zeros kept, as assemble_matrix(bcs=[bc]) does
+    b = load - A[:, on_bnd] @ g[on_bnd]
+    b[on_bnd] = g[on_bnd]
+    A = A.tolil()
+    bidx = np.flatnonzero(on_bnd)
+    keep = sp.diags((~on_bnd).astype(float))
+    A = (keep @ A.tocsr() @ keep + sp.diags(on_bnd.astype(float))).tocsr()
+    A.sort_indices()
+    A = sp.csr_matrix((A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32)), shape=(n, n))
+    lvl = Level(N=M, dim=dim, A=A, b=b.reshape(n, 1), coords=coords, grid_index=idx.copy(), h=h)
+    if seed is None:
+        return lvl
+    rng = np.random.default_rng(seed + 7919 * N)
+    return renumber(lvl, rng.permutation(n))

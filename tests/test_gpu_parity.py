@@ -689,3 +689,38 @@ def test_mass_matrix_norm_and_error_calculators(mg):
     assert abs(mg.err_calculator(u, r, M) - want) <= 1e-13 * want
     ones = np.ones((n1 * n1, 1))
     assert abs(mg.res_calculator(ones, M) - 1.0) <= 1e-13          # sqrt(area of the unit square)
+
+
+@pytest.mark.parametrize("dim,cells,seed", [(2, (4, 8, 16), None), (2, (4, 8, 16), 6), (3, (2, 4, 8), None), (3, (2, 4, 8), 1)])
+def test_p2_matrices_wide_stencils_match_oracle(dim, cells, seed):
+    """BASELINE config 5's element type (no reference implementation: parity unpinned).  P2 stiffness matrices
+    live on the (2N+1)^dim lattice, reach two lattice planes and have up to 51 entries per row, so they take
+    the generic kernels (run-time width, int32 columns; not bit-for-bit symmetric after assembly) and -- where
+    one plane per block would not be block tridiagonal -- the PCG coarsest solve.  Transfers are the lattice
+    injection / Q1 interpolation."""
+    import types
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle
+    levels = {l: poisson.p2_level(N, dim, seed=seed) for l, N in enumerate(cells)}
+    c = 2 * cells[0]
+    bag = types.SimpleNamespace(
+        mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=c,
+        coarsest_level=0, finest_level=2, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+        b_dict={l: L.b for l, L in levels.items()}, mu0=2, mu1=3, mu2=3, omega=0.5,
+        residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None)
+    gi = {l: L.grid_index for l, L in levels.items()}
+    orc = Oracle(bag, gi, dim=dim)
+    f = bag.b_dict[2]
+    want = orc.v_cycle(orc.A_jacobi_sp_dict[2], np.zeros_like(f), f)
+    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi) as dev:
+        info = dev.level_info(2)
+        assert info["ell_width"] == int(np.diff(levels[2].A.indptr).max()) - 0 or info["ell_width"] > 7
+        got = _one_cycle(dev, 2, f)
+        assert rel_l2(got, want) <= TOL_ITER
+        # P2 reproduces the quadratic manufactured solution: it is a fixed point of the cycle
+        exact = levels[2].exact()
+        dev.set_vector(2, "v", exact)
+        dev.residual(2)
+        assert dev.norm2(2, "r") <= 1e-11 * np.linalg.norm(f)
+        dev.vcycle(2, 1)
+        assert rel_l2(dev.get_vector(2, "v"), exact) <= 1e-11
