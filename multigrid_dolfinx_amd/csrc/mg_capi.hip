@@ -444,15 +444,16 @@ void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllAr
     }
 }
 
-// widths with an offset-coded specialisation
-inline bool coded_width(int W) { return W == 5 || W == 7 || W == 15; }
+// offset codes are used for every width up to 64 entries per row (5, 7 and 15 have unrolled kernels)
+inline bool coded_width(int W) { return W >= 1 && W <= 64; }
 
 template <int R>
 void launch_ell_coded_r(int W, int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s) {
     switch (W) {
         case 5: launch_ell_coded_wr<5, R>(mode, dot, nt, a, grid, s); break;
         case 7: launch_ell_coded_wr<7, R>(mode, dot, nt, a, grid, s); break;
-        default: launch_ell_coded_wr<15, R>(mode, dot, nt, a, grid, s); break;
+        case 15: launch_ell_coded_wr<15, R>(mode, dot, nt, a, grid, s); break;
+        default: launch_ell_coded_wr<0, R>(mode, dot, nt, a, grid, s); break;
     }
 }
 

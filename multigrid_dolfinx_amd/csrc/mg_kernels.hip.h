@@ -254,32 +254,48 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
     double dot = 0.0;
     if (sl < a.nslices) {
         const int64_t slice = a.slice0 + sl;
-        const size_t base = (size_t)slice * (size_t)WT * (WAVE * R) + (size_t)lane * R;
-        const size_t cbase = (size_t)slice * (size_t)CW * (WAVE * R) + (size_t)lane * R;
+        const int W = WT > 0 ? WT : a.W;                       // WT == 0: run-time width (wide stencils)
+        const int ncw = WT > 0 ? CW : (a.W + 7) / 8;
+        const size_t base = (size_t)slice * (size_t)W * (WAVE * R) + (size_t)lane * R;
+        const size_t cbase = (size_t)slice * (size_t)ncw * (WAVE * R) + (size_t)lane * R;
         const int64_t row = slice * (WAVE * R) + (int64_t)lane * R;
         const double* xrow = a.x + a.lead + row;
-        DVec<R> v[WT];
-        UVec<R> cw[CW];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) cw[q] = load_u<R, NT>(a.codes + cbase + (size_t)q * (WAVE * R));
-#pragma unroll
-        for (int k = 0; k < WT; ++k) v[k] = load_d<R, NT>(a.vals + base + (size_t)k * (WAVE * R));
         double acc[R], diag[R], xr[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { acc[r] = 0.0; diag[r] = 1.0; xr[r] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < WT; ++k) {
+        auto entry = [&](const UVec<R>& word, int kk, const DVec<R>& val) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int code = (int)((cw[k / 8].d[r] >> (8 * (k % 8))) & 0xffull);
+                const int code = (int)((word.d[r] >> (8 * kk)) & 0xffull);
                 const double xv = xrow[r + s_off[code]];
-                const double val = v[k].d[r];
                 if (MODE != MODE_RESIDUAL) {
                     const bool on_diag = code == a.dcode;
                     if (on_diag) xr[r] = xv;
-                    if (on_diag && val != 0.0) diag[r] = val;
+                    if (on_diag && val.d[r] != 0.0) diag[r] = val.d[r];
                 }
-                acc[r] = fma(val, xv, acc[r]);
+                acc[r] = fma(val.d[r], xv, acc[r]);
+            }
+        };
+        if constexpr (WT > 0) {
+            DVec<R> v[WT > 0 ? WT : 1];
+            UVec<R> cw[CW > 0 ? CW : 1];
+#pragma unroll
+            for (int q = 0; q < CW; ++q) cw[q] = load_u<R, NT>(a.codes + cbase + (size_t)q * (WAVE * R));
+#pragma unroll
+            for (int k = 0; k < WT; ++k) v[k] = load_d<R, NT>(a.vals + base + (size_t)k * (WAVE * R));
+#pragma unroll
+            for (int k = 0; k < WT; ++k) entry(cw[k / 8], k % 8, v[k]);
+        } else {
+            for (int q = 0; q < ncw; ++q) {
+                const UVec<R> word = load_u<R, NT>(a.codes + cbase + (size_t)q * (WAVE * R));
+                const int kend = min(8, W - 8 * q);
+                DVec<R> v[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    if (kk < kend) v[kk] = load_d<R, NT>(a.vals + base + (size_t)(8 * q + kk) * (WAVE * R));
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    if (kk < kend) entry(word, kk, v[kk]);
             }
         }
         tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
