@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--coarse-direct", type=int, default=None, help="0 = PCG on the coarsest level")
     ap.add_argument("--symmetric-storage", type=int, default=None, help="0 = keep lower entries and codes")
     ap.add_argument("--graph", type=int, default=None, help="0 = launch every kernel of a V-cycle eagerly")
+    ap.add_argument("--lds-pad", type=int, default=None, help="experiment: dynamic LDS bytes per block")
     ap.add_argument("--replicate-below", type=int, default=1 << 22,
                     help="levels with fewer unknowns are replicated on every rank")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
@@ -176,6 +177,8 @@ def build_hierarchy(args, rv):
         tuning["symmetric_storage"] = args.symmetric_storage
     if args.graph is not None:
         tuning["graph"] = args.graph
+    if args.lds_pad is not None:
+        tuning["lds_pad"] = args.lds_pad
 
     if rv.world > 1 and args.transport == "rccl":
         # every rank must be able to load RCCL before anybody enters the collective communicator set-up;

@@ -419,20 +419,27 @@ void launch_ell_coded_wr(int mode, bool dot, bool nt, const EllArgs& a, unsigned
     else launch_ell_coded_wrn<WT, R, false>(mode, dot, a, grid, s);
 }
 
+// Dynamic LDS bytes requested per block by the symmetric-diagonal launches on large levels.  The kernels do
+// not use it; it caps the resident blocks per CU at 160 KiB / pad = 5 (20 waves instead of the 28 the
+// register budget allows), which measured 2.4 % faster on the 1025^3 sweep in an interleaved A/B
+// (tools/ab_lds_pad.py: 11.64 vs 11.93 ms; 3 blocks per CU: 14.2 ms) -- fewer concurrent streams per HBM page.
+int g_lds_pad = 32768;
+
 template <int WU, int R, bool NT>
 void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+    const unsigned lds = a.nslices >= 100000 ? (unsigned)g_lds_pad : 0u;
     if (mode == MODE_JACOBI && finest)
-        hipLaunchKernelGGL((sdia_jacobi_finest<WU, R, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_jacobi_finest<WU, R, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else if (mode == MODE_RESIDUAL)
-        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else if (mode == MODE_JACOBI)
-        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else if (mode == MODE_GS)
-        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else if (dot)
-        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else
-        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
 }
 
 template <int R>
@@ -1435,6 +1442,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->strip_slices = (int)value;
     } else if (k == "nontemporal") {
         c->nontemporal = value != 0;
+    } else if (k == "lds_pad") {
+        g_lds_pad = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0;
     } else if (k == "require_diagonal") {

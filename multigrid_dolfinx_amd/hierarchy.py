@@ -79,7 +79,8 @@ class DeviceHierarchy:
                  rows_per_lane: Optional[int] = None, xcd_chunk: Optional[int] = None,
                  offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
                  nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None,
-                 symmetric_storage: Optional[int] = None, graph: Optional[int] = None):
+                 symmetric_storage: Optional[int] = None, graph: Optional[int] = None,
+                 lds_pad: Optional[int] = None):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -105,6 +106,8 @@ class DeviceHierarchy:
             self.set_tuning("symmetric_storage", symmetric_storage)
         if graph is not None:
             self.set_tuning("graph", graph)
+        if lds_pad is not None:
+            self.set_tuning("lds_pad", lds_pad)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):
