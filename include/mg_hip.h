@@ -137,7 +137,23 @@ int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr,
  * in for spsolve on the coarsest level (multigrid.py:239). */
 int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, int smoother,
                   double coarse_rtol, int coarse_maxit, int keep_err);
-/* Tuning knobs of the tile kernels (rows per lane, XCD chunking, ...); see DESIGN.md. */
+/* Tuning and format knobs (defaults in parentheses; DESIGN.md sections 4-6 explain each):
+ *   before any level is set:
+ *     "rows_per_lane"      1 | 2 | 4 rows of a slice per lane (2)
+ *     "offset_codes"       0 keeps int32 column indices (1)
+ *     "symmetric_storage"  0 keeps lower entries even for bit-for-bit symmetric matrices (1)
+ *     "require_diagonal"   0 accepts operators without a diagonal, e.g. D^-1 R for mg_smooth_split (1)
+ *   any time:
+ *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)
+ *     "strip_slices"       slices per XCD strip, 0 = chunked map only (64)
+ *     "nontemporal"        streaming loads for once-read matrix / right-hand-side data (1)
+ *     "lds_pad"            dynamic LDS bytes per block on large levels = occupancy cap (32768)
+ *     "overlap"            halo exchange on the communication stream behind the interior sweep (1)
+ *     "fuse_restrict"      residual evaluated at the coarse nodes only when injecting (1)
+ *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
+ *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
+ *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)
+ * None of them changes results beyond round-off; the tests pin which ones are bit-for-bit neutral. */
 int mg_set_tuning(mg_handle h, const char* key, int64_t value);
 
 /* ---- level queries ------------------------------------------------------------------- */
