@@ -21,6 +21,13 @@
 // instead of being streamed: 88 instead of 116 bytes per row and sweep for 7-point rows.  The
 // arithmetic (entry order, fma chain, IEEE division) is unchanged, so results are bit-identical
 // to the int32-column kernels.
+//
+// Symmetric diagonal storage (the shipped default for bit-for-bit symmetric grid matrices; see the
+// comment above sdia_body): diagonal + upper diagonals only, 32 B of matrix per 7-point row, lower entries
+// re-read as shifted loads of the upper ones: 56 bytes per row and sweep.
+//
+// A level picks the most compact format it qualifies for at set-up (mg_capi.hip: encode_level,
+// repack_sdia); every format has the same four modes (residual, Jacobi, SpMV[+dot], Gauss-Seidel colour).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
