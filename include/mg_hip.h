@@ -149,6 +149,7 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "nontemporal"        streaming loads for once-read matrix / right-hand-side data (1)
  *     "lds_pad"            dynamic LDS bytes per block on large levels = occupancy cap (32768)
  *     "overlap"            halo exchange on the communication stream behind the interior sweep (1)
+ *     "overlap_min_rows"   ... only on levels with at least this many owned rows (4194304)
  *     "fuse_restrict"      residual evaluated at the coarse nodes only when injecting (1)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)

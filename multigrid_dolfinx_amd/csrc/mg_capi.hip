@@ -175,6 +175,7 @@ struct mg_context {
     hipStream_t comm_stream = nullptr;      // halo exchange overlapped with interior sweeps (world > 1)
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     int overlap = 1;
+    int64_t overlap_min_rows = (int64_t)1 << 22;
     std::vector<Level> L;
     int mu1 = 50, mu2 = 50;
     double omega = 2.0 / 3.0;
@@ -676,7 +677,9 @@ int smooth(mg_context* c, int level, int nw) {
     const int64_t S = (int64_t)WAVE * L.R;
     const int64_t lo_end = std::min(L.nslices, (L.g.plane + S - 1) / S);
     const int64_t hi_begin = std::max<int64_t>(lo_end, (L.nloc - L.g.plane) / S);
-    const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream;
+    // below a few million rows a sweep is shorter than the extra launches and event hops of the overlapped
+    // form: exchange in-stream there
+    const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream && L.nloc >= c->overlap_min_rows;
     for (int s = 0; s < nw; ++s) {
         if (!overlap) {
             MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
@@ -1446,6 +1449,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         g_lds_pad = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0;
+    } else if (k == "overlap_min_rows") {
+        c->overlap_min_rows = value;
     } else if (k == "require_diagonal") {
         c->require_diagonal = value != 0;
     } else if (k == "fuse_restrict") {

@@ -67,6 +67,7 @@ def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode
         t = GlooTransport(dist, rank, world)
 
         def comm(h):
+            h.set_tuning("overlap_min_rows", 0)         # tiny grids: still take the overlapped sweep path
             h.set_comm_callbacks(rank, world, t.exchange, t.allreduce, t.allgatherv, replicate_below=replicate_below)
 
         bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=mu, mu2=mu, seed=None if mode == "gen" else 3)

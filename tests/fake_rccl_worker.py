@@ -28,6 +28,7 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
         try:
             def comm(h):
                 h.set_tuning("overlap", overlap)
+                h.set_tuning("overlap_min_rows", 0)     # tiny grids: still take the overlapped sweep path
                 h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
             h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm)
             info = h.level_info(hi)
