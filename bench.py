@@ -73,6 +73,21 @@ def parse():
     return ap.parse_args()
 
 
+class _StdoutToStderr:
+    """gloo announces its connections on the C-level stdout; the contract is ONE JSON line on stdout, so file
+    descriptor 1 points at stderr while torch.distributed sets itself up or tears itself down."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Rendezvous:
     """torch.distributed (gloo) for bootstrap, barrier and max-over-ranks only."""
 
@@ -88,8 +103,10 @@ class Rendezvous:
         self.dist = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            import torch.distributed as dist
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            with _StdoutToStderr():
+                import torch.distributed as dist
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()              # forces the lazy pair connections (and their messages) now
             self.dist = dist
 
     def broadcast_bytes(self, payload):
@@ -113,7 +130,8 @@ class Rendezvous:
 
     def close(self):
         if self.dist is not None:
-            self.dist.destroy_process_group()
+            with _StdoutToStderr():
+                self.dist.destroy_process_group()
 
 
 class GlooCallbacks:
