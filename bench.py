@@ -280,6 +280,12 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # Contract: ONE JSON line on stdout.  RCCL (version banner at communicator set-up), gloo and the HIP
+    # runtime write to the C-level stdout at times, so file descriptor 1 points at stderr for the whole run and
+    # the JSON line goes to the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rv = Rendezvous(args.gpus)
     dim, lo, hi, desc = CONFIGS[args.config]
     t_setup = time.perf_counter()
@@ -356,8 +362,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
     rv.barrier()
     rv.close()
+    sys.stdout.flush()
     if out is not None:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
