@@ -103,6 +103,7 @@ class Rendezvous:
         self.dist = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("NCCL_DEBUG", "WARN")        # RCCL problems show up on stderr
             with _StdoutToStderr():
                 import torch.distributed as dist
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
