@@ -70,7 +70,6 @@ class SlabOracle:
     `replicate_below` unknowns (and always the coarsest) are replicated on every rank."""
 
     def __init__(self, bag, dim, transport, rank, world, replicate_below):
-        import scipy.sparse as sp
         self.bag, self.dim, self.t, self.rank, self.world = bag, dim, transport, rank, world
         self.lo, self.hi = bag.coarsest_level, bag.finest_level
         self.c = bag.coarsest_level_elements_per_dim

@@ -1,6 +1,5 @@
 """CPU checks of the C-ABI boundary: the library loads without a GPU, exports every symbol
 `include/mg_hip.h` declares, and refuses to compute without a device (no CPU fallback)."""
-import ctypes as C
 import os
 import re
 

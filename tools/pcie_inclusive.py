@@ -3,7 +3,6 @@ import sys, time, numpy as np
 sys.path.insert(0, '.')
 from multigrid_dolfinx_amd import poisson
 from multigrid_dolfinx_amd import multigrid as mg
-from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
 dim, lo, hi = 3, 2, 4
 bag = poisson.make_hierarchy(dim, lo, hi, c=8, mu1=50, mu2=50)
 for l in bag.A_sp_dict: bag.A_jacobi_sp_dict[l] = (None, None, l)
