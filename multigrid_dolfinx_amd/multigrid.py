@@ -300,12 +300,32 @@ def _fmg(level, f_h, cycles_tol):
 
 def FullMultiGrid(A_h, f_h):
     """Full multigrid (`multigrid.py:271-307`): below the finest level `mu0` V-cycles per level, on the
-    finest level V-cycles until the residual norm is <= 1e-11 (`:296`; l2 norm here).  Appends the
+    finest level V-cycles until the residual norm is <= 1e-11 (`:296`).  The norm is the l2 norm, or -- when
+    `V_fine_dolfx` holds the P1 mass matrix of the finest mesh instead of a dolfinx function space -- the
+    reference's L2(Omega) norm `sqrt(r^T M r)`, with `u_exact_fine` (nodal values) feeding the error history
+    exactly as `:292-293` does.  Appends the
     per-cycle residual norm to `residual_per_V_cycle_finest` and the iteration count to
     `iter_count_for_diff_num_elems_<levels>_levels.csv`, as the reference does (`:295-301`)."""
     level = A_h[2]
     on_finest = level == finest_level
-    h, hist = _fmg(level, f_h, _options["stop_tol"] if on_finest else 0.0)
+    if on_finest and level > coarsest_level and sp.issparse(V_fine_dolfx):
+        # the reference's own stop test: L2(Omega) norms through `res_calculator` / `err_calculator`
+        # (multigrid.py:288-296), with the P1 mass matrix standing in for the dolfinx function space
+        h, _ = _fmg(level - 1, b_dict[level - 1], 0.0)
+        h.set_vector(level, "f", _column(f_h))
+        h.prolong(level, add=False)
+        h.copy_vector(level, "v", "err")
+        hist = []
+        for _ in range(_options["max_cycles"]):
+            h.vcycle(level, 1)
+            h.residual(level)
+            if u_exact_fine is not None and error_per_V_cycle_finest is not None:
+                error_per_V_cycle_finest.append(err_calculator(h.get_vector(level, "v"), u_exact_fine, V_fine_dolfx))
+            hist.append(res_calculator(h.get_vector(level, "r"), V_fine_dolfx))
+            if hist[-1] <= _options["stop_tol"]:
+                break
+    else:
+        h, hist = _fmg(level, f_h, _options["stop_tol"] if on_finest else 0.0)
     if on_finest and level > coarsest_level:
         if residual_per_V_cycle_finest is not None:
             residual_per_V_cycle_finest.extend(float(x) for x in hist)

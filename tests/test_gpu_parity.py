@@ -728,3 +728,41 @@ def test_p2_matrices_wide_stencils_match_oracle(dim, cells, seed):
         assert dev.norm2(2, "r") <= 1e-11 * np.linalg.norm(f)
         dev.vcycle(2, 1)
         assert rel_l2(dev.get_vector(2, "v"), exact) <= 1e-11
+
+
+def test_full_multigrid_with_the_reference_norms(mg, tmp_path, monkeypatch):
+    """FullMultiGrid's stop test in the reference's own terms (multigrid.py:288-302): residual and error in the
+    L2(Omega) norm, here through the P1 mass matrix handed over in the `V_fine_dolfx` slot."""
+    import scipy.sparse as sps
+    monkeypatch.chdir(tmp_path)
+    bag = poisson.make_hierarchy(2, 1, 3, c=4, mu0=2, mu1=4, mu2=4, seed=2, with_dicts=True)
+    for l, a in bag.A_sp_dict.items():
+        bag.A_jacobi_sp_dict[l] = mg.getJacobiMatrices(a)
+    N = 32
+    h = 1.0 / N
+    lvl = bag.levels[3]
+    ij = np.rint(lvl.coords[:, :2] * N).astype(int)
+    node = {(i, j): d for d, (i, j) in enumerate(map(tuple, ij))}
+    rows, cols, vals = [], [], []
+    loc = (h * h / 24.0) * (np.ones((3, 3)) + np.eye(3))
+    for j in range(N):
+        for i in range(N):
+            for tri in (((i, j), (i + 1, j), (i + 1, j + 1)), ((i, j), (i + 1, j + 1), (i, j + 1))):
+                t = [node[p] for p in tri]
+                for a in range(3):
+                    for b in range(3):
+                        rows.append(t[a]); cols.append(t[b]); vals.append(loc[a, b])
+    M = sps.csr_matrix((vals, (rows, cols)), shape=(lvl.n, lvl.n))
+    M.sum_duplicates()
+    bag.V_fine_dolfx = M
+    bag.u_exact_fine = lvl.exact()
+    mg.configure(restriction="full_weighting", stop_tol=1e-9)
+    mg.initialize_problem(bag)
+    u = mg.FullMultiGrid(bag.A_jacobi_sp_dict[3], bag.b_dict[3])
+    res, err = bag.residual_per_V_cycle_finest, bag.error_per_V_cycle_finest
+    assert len(res) == len(err) >= 1 and res[-1] <= 1e-9 and all(r > 1e-9 for r in res[:-1])
+    r = bag.b_dict[3] - bag.A_sp_dict[3][0].dot(u)
+    assert abs(res[-1] - float(np.sqrt((r.T @ (M @ r)).item()))) <= 1e-6 * res[-1] + 1e-15
+    e = u - lvl.exact()
+    assert abs(err[-1] - float(np.sqrt((e.T @ (M @ e)).item()))) <= 1e-9
+    assert err[-1] < err[0]
