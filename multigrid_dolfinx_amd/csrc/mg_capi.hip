@@ -4,6 +4,7 @@
 #include "../../include/mg_hip.h"
 #include "mg_kernels.hip.h"
 #include "mg_direct.hip.h"
+#include "mg_jacobi2.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -206,6 +207,10 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
+    int64_t fuse_min_rows = (int64_t)1 << 24;
+    int fuse_shape = 0;             // 0: 8 waves x 2 lines, 1: 16 waves x 1 line
+    int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -657,6 +662,59 @@ DVector* pick(Level& L, int which) {
     }
 }
 
+// Two sweeps in one pass (mg_jacobi2.hip.h): whole, undistributed 3-D levels whose stored diagonals are exactly
+// {0, +1, +nx, +plane}.
+bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
+    if (!c->fuse_sweeps || !L.sdia || L.wu != 4 || L.flat) return false;
+    if (!L.replicated && c->comm.active()) return false;
+    if (L.g.ny < 3 || L.g.nz < 3 || L.g.lead != 0) return false;
+    if (L.up[1] != 1 || L.up[2] != L.g.nx || (int64_t)L.up[3] != L.g.plane) return false;
+    return ignore_size || L.nloc >= c->fuse_min_rows;
+}
+
+template <int R, int NW, int LPW>
+int launch_jacobi2_t(mg_context* c, const Level& L, const J2Args& a0) {
+    J2Args a = a0;
+    constexpr int EY = NW * LPW;
+    a.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
+    a.nty = (L.g.ny + EY - 3) / (EY - 2);
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    // enough work items for ~8 rounds over the CUs, segments no shorter than 32 planes
+    int nseg = c->fuse_segments;
+    if (nseg <= 0) nseg = (int)std::max<int64_t>(1, std::min<int64_t>((8 * 256 + ntile - 1) / ntile, L.g.nz / 32));
+    nseg = std::max(1, std::min(nseg, L.g.nz));
+    a.seglen = (L.g.nz + nseg - 1) / nseg;
+    a.nseg = (L.g.nz + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * a.nseg;
+    if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    const unsigned grid = (unsigned)((items + 255) / 256) * 256u;      // whole groups of 8 XCDs x 32 items
+    constexpr size_t lds = j2_lds_bytes<NW, LPW>();
+    static bool attr_set = false;
+    auto* kern_nt = sdia_jacobi2<R, NW, LPW, true>;
+    auto* kern = sdia_jacobi2<R, NW, LPW, false>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (c->nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out = two Jacobi sweeps applied to x
+int launch_jacobi2(mg_context* c, const Level& L, const double* x_rows, const double* f_rows, double* out_rows) {
+    J2Args a{};
+    a.vals = L.dvals; a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.nloc = L.nloc; a.mlead = L.mlead; a.P = L.g.plane;
+    a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nz; a.omega = c->omega;
+    if (L.R == 2) return c->fuse_shape ? launch_jacobi2_t<2, 16, 1>(c, L, a) : launch_jacobi2_t<2, 8, 2>(c, L, a);
+    if (L.R == 1) return c->fuse_shape ? launch_jacobi2_t<1, 16, 1>(c, L, a) : launch_jacobi2_t<1, 8, 2>(c, L, a);
+    return c->fuse_shape ? launch_jacobi2_t<4, 16, 1>(c, L, a) : launch_jacobi2_t<4, 8, 2>(c, L, a);
+}
+
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
@@ -680,7 +738,14 @@ int smooth(mg_context* c, int level, int nw) {
     // below a few million rows a sweep is shorter than the extra launches and event hops of the overlapped
     // form: exchange in-stream there
     const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream && L.nloc >= c->overlap_min_rows;
+    const bool fused = !dist && fused_sweeps_ok(c, L);
     for (int s = 0; s < nw; ++s) {
+        if (fused && s + 1 < nw) {
+            MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows));
+            std::swap(L.v, L.v2);
+            ++s;
+            continue;
+        }
         if (!overlap) {
             MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
             std::swap(L.v, L.v2);
@@ -1455,6 +1520,16 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->require_diagonal = value != 0;
     } else if (k == "fuse_restrict") {
         c->fuse_restrict = value != 0;
+    } else if (k == "fuse_sweeps") {
+        c->fuse_sweeps = value != 0;
+    } else if (k == "fuse_min_rows") {
+        c->fuse_min_rows = value;
+    } else if (k == "fuse_shape") {
+        if (value != 0 && value != 1) return fail("fuse_shape must be 0 or 1");
+        c->fuse_shape = (int)value;
+    } else if (k == "fuse_segments") {
+        if (value < 0) return fail("fuse_segments must be >= 0");
+        c->fuse_segments = (int)value;
     } else if (k == "coarse_direct") {
         c->use_direct = value != 0;
         free_direct(c);
@@ -1946,6 +2021,9 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
     HIP_TRY(hipEventCreate(&e1));
     auto once = [&]() -> int {
         if (k == "jacobi") return launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
+        if (k == "jacobi2")
+            return fused_sweeps_ok(c, L, true) ? launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows)
+                                               : fail("level does not qualify for the two-sweep kernel");
         if (k == "residual") return residual(c, level);
         if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");
         if (k == "prolong") return level > 0 ? prolong(c, level, 1) : fail("level 0");

@@ -1,0 +1,235 @@
+// Two weighted-Jacobi sweeps in one pass over HBM (3-D seven-point levels in symmetric diagonal storage).
+//
+// One sweep of sdia_jacobi_finest moves 56 B per row (32 matrix + 8 x + 8 f + 8 out) and runs at the HBM
+// rate, so the only way to make V(mu1, mu2) faster is to move fewer bytes: here the matrix, f and x are
+// read ONCE for two sweeps and the intermediate iterate never leaves the CU.
+//
+// A workgroup owns a tile of EX x EY grid lines (x, y) and marches through the planes (z).  In row space the
+// seven offsets are {0, +-1, +-nx, +-P}: the +-P neighbours of a cell are the SAME thread's cell one step
+// earlier / later (registers), the +-1 and +-nx neighbours are other threads' cells of the same plane (LDS).
+// At step k the workgroup
+//     A   relaxes plane k+1 once (x, matrix: registers + the LDS image of plane k+1) -> v1[k+1], and completes
+//         the second relaxation of plane k with its last term, a(+P) * v1[k+1]                       -> out
+//     B   starts the second relaxation of plane k+1: every term but the last (v1[k+1] neighbours: LDS)
+//     C   parks the operands of plane k+2, whose loads were issued at the top of the step, in LDS
+// so every global load is issued one full step (~100 KB per CU) before its first use.  Sweep 1 is evaluated
+// on the whole tile, sweep 2 on its interior (TX x TY = (EX-2) x (EY-2)); the one-cell ring of x / matrix
+// entries sweep 1 needs around the tile is loaded by the edge lanes / edge waves.  Everything is done in ROW
+// space (cell (ex, ey, k) <-> row k*P + (ty0+ey)*nx + tx0+ex, whether or not that wraps around a grid line),
+// which is exactly what the one-sweep kernel computes, with the same fma order and the same IEEE division:
+// results are bit-identical to two sdia_jacobi launches.  Tiles are independent (out != x), the plane range
+// is cut into `nseg` segments to have >> 256 work items, each paying 5 warm-up steps.
+#pragma once
+#include "mg_kernels.hip.h"
+
+namespace mgk {
+
+struct J2Args {
+    const double* vals;     // symmetric diagonal storage (WU = 4: diagonal, +1, +nx, +P)
+    const double* x;        // source iterate, row-based (x[row], zero slack on both sides)
+    const double* f;        // row-based
+    double* out;            // row-based, != x
+    int64_t nloc, mlead, P;
+    int nx, ny, nz;
+    int ntx, nty, nseg, seglen;
+    unsigned nitems;
+    double omega;
+};
+
+constexpr int J2_EX = 128;
+
+template <int NW, int LPW> constexpr size_t j2_lds_bytes() {
+    constexpr int EY = NW * LPW, PV = J2_EX + 2;
+    return sizeof(double) * ((size_t)(EY + 2) * PV + 2 * (size_t)EY * PV + 2 * (size_t)(EY + 1) * J2_EX + (size_t)EY * J2_EX);
+}
+
+template <bool NT> __device__ __forceinline__ double j2_ld(const double* p, bool ok) {
+    if (!ok) return 0.0;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int R, int NW, int LPW, bool NT>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
+    constexpr int S = WAVE * R, EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
+    extern __shared__ double j2_smem[];
+    double* const sV0 = j2_smem;                          // (EY+2) x PV       x of one plane, origin (-1,-1)
+    double* const sU1 = sV0 + (EY + 2) * PV;              // 2 x EY x PV       +1 diagonal, origin (-1, 0)
+    double* const sU2 = sU1 + 2 * EY * PV;                // 2 x (EY+1) x EX   +nx diagonal, origin (0,-1)
+    double* const sV1 = sU2 + 2 * (EY + 1) * EX;          // EY x EX           once-relaxed iterate of one plane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // work item: 32 consecutive items per XCD at a time (blocks are dealt round-robin over the 8 XCDs)
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+        id = ((j >> 5) * 8u + xcd) * 32u + (j & 31u);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = (int)(id / ntile);
+    const unsigned t = id % ntile;
+    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
+    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;      // grid position of cell (0, 0)
+
+    // cell c = 2*l + r of this thread: ex = lane + 64 r, ey = wave*LPW + l; everything else is an offset from cell 0
+    const int ey0 = wave * LPW;
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);     // row of cell 0 in plane 0
+    const int lv0 = (ey0 + 1) * PV + lane + 1;                            // cell 0 in sV0; in sU1 it is lv0 - PV
+    const int lw0 = ey0 * EX + lane;                                      // cell 0 in sV1; in sU2 it is lw0 + EX
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
+    auto lvof = [&](int c) -> int { return lv0 + (c >> 1) * PV + 64 * (c & 1); };
+    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
+    unsigned inT = 0;       // bit c: interior cell whose second sweep this tile stores
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
+        if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
+    }
+    const bool hl = lane == 0, hr = lane == 63;
+    const bool wlo = wave == 0, whi = wave == NW - 1;
+
+    auto mat = [&](int64_t row) -> const double* {        // address of the row's diagonal slot
+        const uint64_t m = (uint64_t)(row + a.mlead);
+        return a.vals + (size_t)(m / S) * (4 * S) + (size_t)(m % S);
+    };
+
+    // registers.  plane k: +P diagonal, f, omega/diag, the second sweep's sum up to the +nx term, v1;
+    // planes k+1 and k+2 (in flight): the matrix row and f; x of planes k .. k+3
+    double s0[NC], f0[NC], cf0[NC], ap0[NC], w0[NC];
+    double d1[NC], p1[NC], q1[NC], s1[NC], f1[NC];
+    double d2[NC], p2[NC], q2[NC], s2[NC], f2[NC];
+    double va[NC], vb[NC], vc[NC], vd[NC], w1[NC];
+    double hxv[LPW], hxu[LPW], hyv[2], hyu[2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        s0[c] = f0[c] = cf0[c] = ap0[c] = w0[c] = 0.0;
+        d1[c] = p1[c] = q1[c] = s1[c] = f1[c] = 0.0;
+        va[c] = vb[c] = vc[c] = w1[c] = 0.0;
+    }
+
+    for (int k = z0 - 5; k < z1; ++k) {
+        // ---- issue the loads of plane k+2 (matrix, f, ring) and of plane k+3 (x) ----
+        const int64_t o2 = (int64_t)(k + 2) * a.P, o3 = o2 + a.P;
+        const bool need2 = k + 2 >= z0 - 2 && k + 2 <= z1, need3 = k + 3 <= z1 + 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r2 = rowof(c) + o2, r3 = rowof(c) + o3;
+            const bool ok2 = need2 && r2 >= 0 && r2 < a.nloc;
+            const double* m = mat(ok2 ? r2 : 0);
+            d2[c] = j2_ld<NT>(m, ok2);
+            p2[c] = j2_ld<NT>(m + S, ok2);
+            q2[c] = j2_ld<NT>(m + 2 * S, ok2);
+            s2[c] = j2_ld<NT>(m + 3 * S, ok2);
+            f2[c] = j2_ld<NT>(a.f + r2, ok2);
+            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= 0 && r3 < a.nloc);
+        }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            // x ring: the cell left of ex = 0 (lane 0) and right of ex = EX-1 (lane 63)
+            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o2;
+            const bool okh = need2 && (hl || hr) && hrow >= 0 && hrow < a.nloc;
+            hxv[l] = j2_ld<false>(a.x + hrow, okh);
+            hxu[l] = j2_ld<false>(mat(okh ? hrow : 0) + S, okh && hl);
+        }
+        hyv[0] = hyv[1] = hyu[0] = hyu[1] = 0.0;
+        if (wlo) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int64_t hrow = rowof(r) - a.nx + o2;
+                const bool okh = need2 && hrow >= 0 && hrow < a.nloc;
+                hyv[r] = j2_ld<false>(a.x + hrow, okh);
+                hyu[r] = j2_ld<false>(mat(okh ? hrow : 0) + 2 * S, okh);
+            }
+        } else if (whi) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int64_t hrow = rowof(2 * (LPW - 1) + r) + a.nx + o2;
+                hyv[r] = j2_ld<false>(a.x + hrow, need2 && hrow >= 0 && hrow < a.nloc);
+            }
+        }
+
+        const int sp = (k + 1) & 1;
+        const double* const u1p = sU1 + sp * (EY * PV) - PV;          // indexed like sV0
+        const double* const u2p = sU2 + sp * ((EY + 1) * EX) + EX;    // indexed like sV1
+        // ---- A: first sweep on plane k+1; the second sweep of plane k gets its last (+P) term ----
+        if (k >= z0 - 2) {
+            const int64_t o1 = o2 - a.P;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int iv = lvof(c), iw = lwof(c);
+                double acc = 0.0;
+                acc = fma(s0[c], va[c], acc);                           // -P
+                acc = fma(u2p[iw - EX], sV0[iv - PV], acc);             // -nx
+                acc = fma(u1p[iv - 1], sV0[iv - 1], acc);               // -1
+                const double diag = d1[c] != 0.0 ? d1[c] : 1.0;
+                acc = fma(d1[c], vb[c], acc);
+                acc = fma(p1[c], sV0[iv + 1], acc);                     // +1
+                acc = fma(q1[c], sV0[iv + PV], acc);                    // +nx
+                acc = fma(s1[c], vc[c], acc);                           // +P
+                const double o = vb[c] + (a.omega * (1.0 / diag)) * (f1[c] - acc);
+                const int64_t r1 = rowof(c) + o1;
+                w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
+                sV1[iw] = w1[c];
+                if (k >= z0 && (inT >> c & 1u))
+                    a.out[r1 - a.P] = w0[c] + cf0[c] * (f0[c] - fma(s0[c], w1[c], ap0[c]));
+            }
+        }
+        __syncthreads();
+        // ---- B: second sweep of plane k+1 up to its +nx term (the neighbours of v1[k+1] are in LDS now) ----
+        if (k >= z0 - 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double acc = 0.0;
+                if (inT >> c & 1u) {
+                    const int iv = lvof(c), iw = lwof(c);
+                    acc = fma(s0[c], w0[c], acc);
+                    acc = fma(u2p[iw - EX], sV1[iw - EX], acc);
+                    acc = fma(u1p[iv - 1], sV1[iw - 1], acc);
+                    acc = fma(d1[c], w1[c], acc);
+                    acc = fma(p1[c], sV1[iw + 1], acc);
+                    acc = fma(q1[c], sV1[iw + EX], acc);
+                }
+                ap0[c] = acc;
+            }
+        }
+        // ---- C: park plane k+2 (x arrived a step ago, matrix and ring just now); rotate ----
+        if (k >= z0 - 3) {
+            const int sc = k & 1;
+            double* const u1s = sU1 + sc * (EY * PV) - PV;
+            double* const u2s = sU2 + sc * ((EY + 1) * EX) + EX;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int iv = lvof(c), iw = lwof(c);
+                sV0[iv] = vc[c];
+                u1s[iv] = p2[c];
+                u2s[iw] = q2[c];
+            }
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) {
+                const int rowv = (ey0 + l + 1) * PV;
+                if (hl) { sV0[rowv] = hxv[l]; u1s[rowv] = hxu[l]; }
+                if (hr) sV0[rowv + EX + 1] = hxv[l];
+            }
+            if (wlo) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; u2s[lane + 64 * r - EX] = hyu[r]; }
+            } else if (whi) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double diag = d1[c] != 0.0 ? d1[c] : 1.0;
+            cf0[c] = a.omega * (1.0 / diag);
+            s0[c] = s1[c]; f0[c] = f1[c]; w0[c] = w1[c];
+            d1[c] = d2[c]; p1[c] = p2[c]; q1[c] = q2[c]; s1[c] = s2[c]; f1[c] = f2[c];
+            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mgk

@@ -766,3 +766,46 @@ def test_full_multigrid_with_the_reference_norms(mg, tmp_path, monkeypatch):
     e = u - lvl.exact()
     assert abs(err[-1] - float(np.sqrt((e.T @ (M @ e)).item()))) <= 1e-9
     assert err[-1] < err[0]
+
+
+@pytest.mark.parametrize("c,lo,hi", [(8, 2, 4), (5, 1, 3), (7, 1, 4)])
+def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
+    """mg_jacobi2.hip.h: two Jacobi sweeps per pass over the matrix (tile + plane march, intermediate iterate in
+    LDS / registers) must reproduce two launches of the one-sweep kernel bit for bit -- for every tile shape,
+    plane segmentation, odd sweep count and grid size that is not a multiple of the tile."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(c)
+    want = {}
+    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3, fuse_shape=1),
+                dict(fuse_segments=5, nontemporal=0), dict(rows_per_lane=1), dict(rows_per_lane=4, fuse_shape=1)]
+    for kw in variants:
+        tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
+        make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
+        with DeviceHierarchy.synthetic(3, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
+            dev.set_tuning("fuse_min_rows", 0)
+            for k, v in tune.items():
+                dev.set_tuning(k, v)
+            for level in range(lo + 1, hi + 1):
+                info = dev.level_info(level)
+                assert info["symmetric_diagonals"] == 4
+                n = info["n_global"]
+                if (level, "v") not in want:
+                    want[level, "v"] = rng.standard_normal(n)
+                    want[level, "f"] = rng.standard_normal(n)
+                for nw in (2, 3, 6):
+                    dev.set_vector(level, "v", want[level, "v"])
+                    dev.set_vector(level, "f", want[level, "f"])
+                    dev.smooth(level, nw)
+                    got = dev.get_vector(level, "v")
+                    if kw == variants[0]:
+                        want[level, nw] = got
+                    else:
+                        assert np.array_equal(got, want[level, nw]), (kw, level, nw)
+            # whole cycles through the graph cache with an odd number of buffer swaps per smoother call
+            dev.set_params(3, 5, 2.0 / 3.0)
+            dev.zero_vector(hi, "v")
+            res = dev.vcycle(hi, 3, residuals=True)
+            if kw == variants[0]:
+                want["res"] = res
+            else:
+                assert np.all(np.abs(res - want["res"]) <= 1e-13 * want["res"]), kw
