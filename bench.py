@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--offset-codes", type=int, default=None, help="0 = int32 column indices")
     ap.add_argument("--strip-slices", type=int, default=None, help="XCD strip traversal (0 = off)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="any other mg_set_tuning knob, e.g. --tune fuse_sweeps=0 (one Jacobi sweep per launch)")
     ap.add_argument("--nontemporal", type=int, default=None)
     ap.add_argument("--coarse-direct", type=int, default=None, help="0 = PCG on the coarsest level")
     ap.add_argument("--symmetric-storage", type=int, default=None, help="0 = keep lower entries and codes")
@@ -198,6 +200,9 @@ def build_hierarchy(args, rv):
         tuning["graph"] = args.graph
     if args.lds_pad is not None:
         tuning["lds_pad"] = args.lds_pad
+    for kv in args.tune:
+        key, value = kv.split("=")
+        tuning[key] = int(value)
 
     if rv.world > 1 and args.transport == "rccl":
         # every rank must be able to load RCCL before anybody enters the collective communicator set-up;
@@ -302,19 +307,26 @@ def main():
     info = h.level_info(hi)
     jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
     res_ms = h.time_kernel("residual", hi, args.kernel_reps)
+    try:        # the smoother pairs sweeps on this level (mg_jacobi2.hip.h): that launch is the dominant one
+        pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
+    except Exception:
+        pair_ms = None
     n_loc, z_loc = info["n_local"], info["nnz_nonzero"]
     # ALGORITHMIC bytes (ELL form): values + int32 columns, read v f D^-1, write v -- what a
     # plain ELL sweep moves; the shipped formats move less (see roofline.traffic and DESIGN.md section 5)
     bytes_jacobi = 12 * z_loc + 32 * n_loc
     bytes_resid = 12 * z_loc + 24 * n_loc
-    achieved = bytes_jacobi / (jac_ms * 1e-3) / 1e9
+    sweeps_per_launch = 2 if pair_ms else 1
+    dom_ms = pair_ms if pair_ms else jac_ms
+    bytes_launch = sweeps_per_launch * bytes_jacobi
+    achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             key = f"{args.config}_gpus{args.gpus}"
-            traffic = t.get(key, {}).get("jacobi_hbm_bytes_per_launch")
+            traffic = t.get(key, {}).get("jacobi2_hbm_bytes_per_launch" if pair_ms else "jacobi_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -343,17 +355,19 @@ def main():
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("sdia_apply" if info["symmetric_diagonals"] else
+                         "kernel": "sdia_jacobi2<...> (two fine-level weighted-Jacobi sweeps per launch)" if pair_ms else
+                                   ("sdia_apply" if info["symmetric_diagonals"] else
                                     "ell_apply_coded" if info["offset_codes"] else "ell_apply")
                                    + "<..., MODE_JACOBI> (fine-level weighted-Jacobi sweep)",
+                         "sweeps_per_launch": sweeps_per_launch, "single_sweep_kernel_ms": jac_ms,
                          "storage": ("symmetric diagonals" if info["symmetric_diagonals"] else
                                      "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
-                         "kernel_ms": jac_ms, "algorithmic_bytes_per_launch": bytes_jacobi,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
                          # what the kernel really moves (PMC, profiles/traffic.json) per second: the shipped
                          # formats move fewer bytes than the algorithmic count, hence frac can exceed 1
-                         "traffic_GBs": (traffic / (jac_ms * 1e-3) / 1e9) if traffic else None,
-                         "traffic_frac_of_peak": (traffic / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_GBs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "residual_kernel_ms": res_ms,
                          "residual_achieved_GBs": bytes_resid / (res_ms * 1e-3) / 1e9},
             "v22_cycles_per_s": v22_per_s, "residual_l2_after": res_after, "rhs_l2": f_norm,

@@ -211,6 +211,7 @@ struct mg_context {
     int64_t fuse_min_rows = (int64_t)1 << 24;
     int fuse_shape = 0;             // 0: 8 waves x 2 lines, 1: 16 waves x 1 line
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
+    int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -681,7 +682,7 @@ int launch_jacobi2_t(mg_context* c, const Level& L, const J2Args& a0) {
     const int64_t ntile = (int64_t)a.ntx * a.nty;
     // enough work items for ~8 rounds over the CUs, segments no shorter than 32 planes
     int nseg = c->fuse_segments;
-    if (nseg <= 0) nseg = (int)std::max<int64_t>(1, std::min<int64_t>((8 * 256 + ntile - 1) / ntile, L.g.nz / 32));
+    if (nseg <= 0) nseg = (int)std::max<int64_t>(1, std::min<int64_t>((16 * 256 + ntile - 1) / ntile, L.g.nz / 32));
     nseg = std::max(1, std::min(nseg, L.g.nz));
     a.seglen = (L.g.nz + nseg - 1) / nseg;
     a.nseg = (L.g.nz + a.seglen - 1) / a.seglen;
@@ -698,7 +699,7 @@ int launch_jacobi2_t(mg_context* c, const Level& L, const J2Args& a0) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (c->nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    if (c->fuse_nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1527,6 +1528,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_shape") {
         if (value != 0 && value != 1) return fail("fuse_shape must be 0 or 1");
         c->fuse_shape = (int)value;
+    } else if (k == "fuse_nontemporal") {
+        c->fuse_nontemporal = value != 0;
     } else if (k == "fuse_segments") {
         if (value < 0) return fail("fuse_segments must be >= 0");
         c->fuse_segments = (int)value;
@@ -2021,9 +2024,10 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
     HIP_TRY(hipEventCreate(&e1));
     auto once = [&]() -> int {
         if (k == "jacobi") return launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
-        if (k == "jacobi2")
-            return fused_sweeps_ok(c, L, true) ? launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows)
-                                               : fail("level does not qualify for the two-sweep kernel");
+        // "jacobi2": only where mg_smooth itself pairs sweeps on this level; "jacobi2!": wherever the kernel applies
+        if (k == "jacobi2" || k == "jacobi2!")
+            return fused_sweeps_ok(c, L, k == "jacobi2!") ? launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows)
+                                                           : fail("level does not use the two-sweep kernel");
         if (k == "residual") return residual(c, level);
         if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");
         if (k == "prolong") return level > 0 ? prolong(c, level, 1) : fail("level 0");

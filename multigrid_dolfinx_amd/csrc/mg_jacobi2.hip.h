@@ -43,10 +43,12 @@ template <int NW, int LPW> constexpr size_t j2_lds_bytes() {
     return sizeof(double) * ((size_t)(EY + 2) * PV + 2 * (size_t)EY * PV + 2 * (size_t)(EY + 1) * J2_EX + (size_t)EY * J2_EX);
 }
 
-template <bool NT> __device__ __forceinline__ double j2_ld(const double* p, bool ok) {
-    if (!ok) return 0.0;
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+// Loads never branch: a row outside the level reads a stored zero instead (`zero`: the slack in front of a
+// vector / the lead rows of the matrix), so all loads of a step are issued back to back.
+template <bool NT> __device__ __forceinline__ double j2_ld(const double* p, bool ok, const double* zero) {
+    const double* q = ok ? p : zero;
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
 }
 
 template <int R, int NW, int LPW, bool NT>
@@ -94,6 +96,9 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
         const uint64_t m = (uint64_t)(row + a.mlead);
         return a.vals + (size_t)(m / S) * (4 * S) + (size_t)(m % S);
     };
+    const double* const zx = a.x - 1;                     // zero slack in front of the vectors
+    const double* const zf = a.f - 1;
+    const double* const zm = mat(-1);                     // a zero lead row of the matrix (all four slots)
 
     // registers.  plane k: +P diagonal, f, omega/diag, the second sweep's sum up to the +nx term, v1;
     // planes k+1 and k+2 (in flight): the matrix row and f; x of planes k .. k+3
@@ -117,37 +122,29 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
         for (int c = 0; c < NC; ++c) {
             const int64_t r2 = rowof(c) + o2, r3 = rowof(c) + o3;
             const bool ok2 = need2 && r2 >= 0 && r2 < a.nloc;
-            const double* m = mat(ok2 ? r2 : 0);
-            d2[c] = j2_ld<NT>(m, ok2);
-            p2[c] = j2_ld<NT>(m + S, ok2);
-            q2[c] = j2_ld<NT>(m + 2 * S, ok2);
-            s2[c] = j2_ld<NT>(m + 3 * S, ok2);
-            f2[c] = j2_ld<NT>(a.f + r2, ok2);
-            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= 0 && r3 < a.nloc);
+            const double* m = ok2 ? mat(r2) : zm;
+            d2[c] = j2_ld<NT>(m, true, zm);
+            p2[c] = j2_ld<NT>(m + S, true, zm);
+            q2[c] = j2_ld<NT>(m + 2 * S, true, zm);
+            s2[c] = j2_ld<NT>(m + 3 * S, true, zm);
+            f2[c] = j2_ld<NT>(a.f + r2, ok2, zf);
+            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= 0 && r3 < a.nloc, zx);
         }
 #pragma unroll
         for (int l = 0; l < LPW; ++l) {
             // x ring: the cell left of ex = 0 (lane 0) and right of ex = EX-1 (lane 63)
             const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o2;
             const bool okh = need2 && (hl || hr) && hrow >= 0 && hrow < a.nloc;
-            hxv[l] = j2_ld<false>(a.x + hrow, okh);
-            hxu[l] = j2_ld<false>(mat(okh ? hrow : 0) + S, okh && hl);
+            hxv[l] = j2_ld<false>(a.x + hrow, okh, zx);
+            hxu[l] = j2_ld<false>((okh && hl ? mat(hrow) : zm) + S, true, zm);
         }
-        hyv[0] = hyv[1] = hyu[0] = hyu[1] = 0.0;
-        if (wlo) {
+        // y ring: the line below ey = 0 (first wave) and above ey = EY-1 (last wave)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int64_t hrow = rowof(r) - a.nx + o2;
-                const bool okh = need2 && hrow >= 0 && hrow < a.nloc;
-                hyv[r] = j2_ld<false>(a.x + hrow, okh);
-                hyu[r] = j2_ld<false>(mat(okh ? hrow : 0) + 2 * S, okh);
-            }
-        } else if (whi) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int64_t hrow = rowof(2 * (LPW - 1) + r) + a.nx + o2;
-                hyv[r] = j2_ld<false>(a.x + hrow, need2 && hrow >= 0 && hrow < a.nloc);
-            }
+        for (int r = 0; r < 2; ++r) {
+            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o2;
+            const bool okh = need2 && (wlo || whi) && hrow >= 0 && hrow < a.nloc;
+            hyv[r] = j2_ld<false>(a.x + hrow, okh, zx);
+            hyu[r] = j2_ld<false>((okh && wlo ? mat(hrow) : zm) + 2 * S, true, zm);
         }
 
         const int sp = (k + 1) & 1;

@@ -80,7 +80,7 @@ class DeviceHierarchy:
                  offset_codes: Optional[int] = None, strip_slices: Optional[int] = None,
                  nontemporal: Optional[int] = None, coarse_direct: Optional[int] = None,
                  symmetric_storage: Optional[int] = None, graph: Optional[int] = None,
-                 lds_pad: Optional[int] = None):
+                 lds_pad: Optional[int] = None, **more_tuning):
         self._lib = load()
         self.dim = dim
         self.c = c
@@ -108,6 +108,8 @@ class DeviceHierarchy:
             self.set_tuning("graph", graph)
         if lds_pad is not None:
             self.set_tuning("lds_pad", lds_pad)
+        for key, value in more_tuning.items():        # any other mg_set_tuning key (fuse_sweeps, fuse_segments ...)
+            self.set_tuning(key, value)
 
     # ---- life cycle ---------------------------------------------------------------------
     def close(self):

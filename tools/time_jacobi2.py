@@ -15,12 +15,12 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=2, mu2=2) as dev:
     out["jacobi_ms"] = dev.time_kernel("jacobi", hi, reps)
     print(out, flush=True)
     for shape in (0, 1):
-        for seg in (0, 1, 2, 4, 8):
+        for seg in (0, 4, 8, 12, 16, 24):
             for nt in (1, 0):
                 dev.set_tuning("fuse_shape", shape)
                 dev.set_tuning("fuse_segments", seg)
-                dev.set_tuning("nontemporal", nt)
-                ms = dev.time_kernel("jacobi2", hi, reps)
+                dev.set_tuning("fuse_nontemporal", nt)
+                ms = dev.time_kernel("jacobi2!", hi, reps)
                 out[f"jacobi2_shape{shape}_seg{seg}_nt{nt}_ms"] = ms
                 print(f"shape {shape} seg {seg} nt {nt}: {ms:.3f} ms per pair = {ms / 2:.3f} per sweep, "
                       f"{2 * 56 * n / ms / 1e9:.2f} TB/s one-sweep-equivalent", flush=True)
