@@ -143,6 +143,7 @@ struct Level {
     int64_t mlead = 0, mslices = 0;
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
+    DVector sw;                             // once-relaxed boundary planes of a slab (paired sweeps, world > 1)
     int* perm = nullptr;
     unsigned long long nnz_stored = 0, nnz_nonzero = 0;
     // per-rank plane ownership (for gathers): k-plane boundaries s[0..world]
@@ -174,7 +175,7 @@ struct mg_context {
     int dim = 2, nlev = 0, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;      // halo exchange overlapped with interior sweeps (world > 1)
-    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_vhalo = nullptr;
     int overlap = 1;
     int64_t overlap_min_rows = (int64_t)1 << 22;
     std::vector<Level> L;
@@ -387,6 +388,7 @@ void free_level(mg_context* c, Level& L) {
     vec_free(c, L, &L.f);
     vec_free(c, L, &L.err);
     vec_free(c, L, &L.ftrue);
+    vec_free(c, L, &L.sw);
     L.set = false;
     L.has_matrix = false;
 }
@@ -667,28 +669,33 @@ DVector* pick(Level& L, int which) {
 // {0, +1, +nx, +plane}.
 bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     if (!c->fuse_sweeps || !L.sdia || L.wu != 4 || L.flat) return false;
-    if (!L.replicated && c->comm.active()) return false;
-    if (L.g.ny < 3 || L.g.nz < 3 || L.g.lead != 0) return false;
+    if (L.g.nx < 32 || L.g.ny < 32 || L.g.nk < 8) return false;    // zero slack >= 3 slices, slabs >= 8 planes
     if (L.up[1] != 1 || L.up[2] != L.g.nx || (int64_t)L.up[3] != L.g.plane) return false;
     return ignore_size || L.nloc >= c->fuse_min_rows;
 }
 
+constexpr int kJ2Lines = 16;        // grid lines per tile of both launch shapes (8 waves x 2, 16 waves x 1)
+
+// Tiles per plane segment and the cut of the owned planes into segments: enough work items for ~16 rounds over
+// the CUs, segments no shorter than 32 planes (each pays 5 warm-up steps).
+void jacobi2_plan(const mg_context* c, const Level& L, int* ntx, int* nty, int* nseg, int* seglen) {
+    *ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
+    *nty = (L.g.ny + kJ2Lines - 3) / (kJ2Lines - 2);
+    const int64_t ntile = (int64_t)*ntx * *nty;
+    int n = c->fuse_segments;
+    if (n <= 0) n = (int)std::max<int64_t>(1, std::min<int64_t>((16 * 256 + ntile - 1) / ntile, L.g.nk / 32));
+    n = std::max(1, std::min(n, L.g.nk));
+    *seglen = (L.g.nk + n - 1) / n;
+    *nseg = (L.g.nk + *seglen - 1) / *seglen;
+}
+
 template <int R, int NW, int LPW>
-int launch_jacobi2_t(mg_context* c, const Level& L, const J2Args& a0) {
-    J2Args a = a0;
-    constexpr int EY = NW * LPW;
-    a.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
-    a.nty = (L.g.ny + EY - 3) / (EY - 2);
-    const int64_t ntile = (int64_t)a.ntx * a.nty;
-    // enough work items for ~8 rounds over the CUs, segments no shorter than 32 planes
-    int nseg = c->fuse_segments;
-    if (nseg <= 0) nseg = (int)std::max<int64_t>(1, std::min<int64_t>((16 * 256 + ntile - 1) / ntile, L.g.nz / 32));
-    nseg = std::max(1, std::min(nseg, L.g.nz));
-    a.seglen = (L.g.nz + nseg - 1) / nseg;
-    a.nseg = (L.g.nz + a.seglen - 1) / a.seglen;
-    const int64_t items = ntile * a.nseg;
+int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg) {
+    static_assert(NW * LPW == kJ2Lines, "tile height");
+    const int64_t items = (int64_t)a.ntx * a.nty * nseg;
     if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
-    a.nitems = (unsigned)items;
+    J2Args b = a;
+    b.nitems = (unsigned)items;
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;      // whole groups of 8 XCDs x 32 items
     constexpr size_t lds = j2_lds_bytes<NW, LPW>();
     static bool attr_set = false;
@@ -699,21 +706,35 @@ int launch_jacobi2_t(mg_context* c, const Level& L, const J2Args& a0) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (c->fuse_nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
-    else hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    if (c->fuse_nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// out = two Jacobi sweeps applied to x
-int launch_jacobi2(mg_context* c, const Level& L, const double* x_rows, const double* f_rows, double* out_rows) {
+// out = two Jacobi sweeps applied to x, for the plane segments [seg_lo, seg_hi) (default: all)
+// (slabs: the second sweep is stored for the rows [st_lo, st_hi) only and the once-relaxed iterate of the rows
+// within reach of the others goes to v1_rows, see smooth())
+int launch_jacobi2(mg_context* c, const Level& L, const double* x_rows, const double* f_rows, double* out_rows,
+                   int64_t st_lo = 0, int64_t st_hi = INT64_MAX, double* v1_rows = nullptr, int seg_lo = 0, int seg_hi = -1) {
     J2Args a{};
     a.vals = L.dvals; a.x = x_rows; a.f = f_rows; a.out = out_rows;
     a.nloc = L.nloc; a.mlead = L.mlead; a.P = L.g.plane;
-    a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nz; a.omega = c->omega;
-    if (L.R == 2) return c->fuse_shape ? launch_jacobi2_t<2, 16, 1>(c, L, a) : launch_jacobi2_t<2, 8, 2>(c, L, a);
-    if (L.R == 1) return c->fuse_shape ? launch_jacobi2_t<1, 16, 1>(c, L, a) : launch_jacobi2_t<1, 8, 2>(c, L, a);
-    return c->fuse_shape ? launch_jacobi2_t<4, 16, 1>(c, L, a) : launch_jacobi2_t<4, 8, 2>(c, L, a);
+    a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
+    a.zero = L.f.raw;
+    a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.slo = -L.halo_lo;
+    a.st_lo = st_lo; a.st_hi = st_hi; a.v1out = v1_rows;
+    a.k1_lo = st_lo + L.g.plane + L.g.nx + 2; a.k1_hi = st_hi - L.g.plane - L.g.nx - 2;
+    int nseg = 0;
+    jacobi2_plan(c, L, &a.ntx, &a.nty, &nseg, &a.seglen);
+    if (seg_hi < 0) seg_hi = nseg;
+    if (seg_lo < 0 || seg_hi > nseg) return fail("bad segment range");
+    if (seg_hi <= seg_lo) return 0;
+    a.seg0 = seg_lo;
+    const int n = seg_hi - seg_lo;
+    if (L.R == 2) return c->fuse_shape ? launch_jacobi2_t<2, 16, 1>(c, a, n) : launch_jacobi2_t<2, 8, 2>(c, a, n);
+    if (L.R == 1) return c->fuse_shape ? launch_jacobi2_t<1, 16, 1>(c, a, n) : launch_jacobi2_t<1, 8, 2>(c, a, n);
+    return c->fuse_shape ? launch_jacobi2_t<4, 16, 1>(c, a, n) : launch_jacobi2_t<4, 8, 2>(c, a, n);
 }
 
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
@@ -739,13 +760,74 @@ int smooth(mg_context* c, int level, int nw) {
     // below a few million rows a sweep is shorter than the extra launches and event hops of the overlapped
     // form: exchange in-stream there
     const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream && L.nloc >= c->overlap_min_rows;
-    const bool fused = !dist && fused_sweeps_ok(c, L);
+    const bool fused = fused_sweeps_ok(c, L) && (!dist || hi_begin > lo_end);
+    if (fused && dist && nw > 1) MG_TRY(vec_alloc(c, L, &L.sw));
+    int j2_nseg = 0;
+    if (fused) {
+        int ntx, nty, seglen;
+        jacobi2_plan(c, L, &ntx, &nty, &j2_nseg, &seglen);
+        // the first / last segment must hold every row whose once-relaxed value travels or whose second sweep waits
+        // for the neighbours (launch_jacobi2: k1_lo, k1_hi), else all segments go in one launch
+        const int64_t reach = L.g.plane + L.g.nx + 2;
+        if (dist && ((int64_t)seglen * L.g.plane < lo_end * S + reach ||
+                     (int64_t)(j2_nseg - 1) * seglen * L.g.plane > hi_begin * S - reach))
+            j2_nseg = 1;
+    }
+    bool vhalo_pending = false;         // an exchange of v's halos is in flight on the communication stream
     for (int s = 0; s < nw; ++s) {
         if (fused && s + 1 < nw) {
-            MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows));
+            if (!dist) {
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows));
+            } else if (overlap && j2_nseg >= 4) {
+                // both exchanges of a pair travel while interior plane segments are relaxed:
+                //   boundary segments -> [v1 planes travel | interior, first half] -> boundary slices' 2nd sweep
+                //   -> [v2 planes travel | interior, second half]; the next pair (or the exit) waits for the latter
+                const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
+                const int64_t st_lo = lo ? lo_end * S : 0, st_hi = hi ? hi_begin * S : INT64_MAX;
+                const int mid = 1 + (j2_nseg - 2) / 2;
+                if (vhalo_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, 0, 1));
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, j2_nseg - 1, j2_nseg));
+                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+                MG_TRY(exchange_halo(c, L, L.sw, c->comm_stream));
+                HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, 1, mid));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+                if (lo) MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
+                if (hi)
+                    MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
+                                      L.nslices - hi_begin));
+                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+                MG_TRY(exchange_halo(c, L, L.v2, c->comm_stream));
+                HIP_TRY(hipEventRecord(c->ev_vhalo, c->comm_stream));
+                vhalo_pending = true;
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, mid, j2_nseg - 1));
+                std::swap(L.v, L.v2);
+                ++s;
+                continue;
+            } else {
+                // the rows of the slices that hold the first / last owned plane need the neighbours' once-relaxed
+                // planes for their second sweep: the pass leaves them out and parks v1 around them in `sw`, whose
+                // halos are then exchanged like any iterate's, and the one-sweep kernel finishes those slices
+                const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
+                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, lo ? lo_end * S : 0,
+                                      hi ? hi_begin * S : INT64_MAX, L.sw.rows));
+                MG_TRY(exchange_halo(c, L, L.sw));
+                if (lo) MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
+                if (hi)
+                    MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
+                                      L.nslices - hi_begin));
+            }
             std::swap(L.v, L.v2);
+            MG_TRY(exchange_halo(c, L, L.v));
             ++s;
             continue;
+        }
+        if (vhalo_pending) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
+            vhalo_pending = false;
         }
         if (!overlap) {
             MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
@@ -766,6 +848,7 @@ int smooth(mg_context* c, int level, int nw) {
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
         std::swap(L.v, L.v2);
     }
+    if (vhalo_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
     return 0;
 }
 
@@ -1345,6 +1428,7 @@ int mg_create(int n_levels, int dim, int device, mg_handle* out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_vhalo, hipEventDisableTiming));
     MG_TRY(dev_alloc(c, &c->partials, 2 * kMaxParts));
     MG_TRY(dev_alloc(c, &c->scalars, 8));
     MG_TRY(dev_alloc(c, &c->done, 1));
@@ -1376,6 +1460,7 @@ int mg_destroy(mg_handle c) {
     if (c->comm.nccl) g_rccl.CommDestroy(c->comm.nccl);
     if (c->ev_boundary) (void)hipEventDestroy(c->ev_boundary);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->ev_vhalo) (void)hipEventDestroy(c->ev_vhalo);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -30,8 +30,15 @@ struct J2Args {
     const double* f;        // row-based
     double* out;            // row-based, != x
     int64_t nloc, mlead, P;
+    // slabs (one rank's planes of a distributed level): x also holds the neighbours' planes in rows [xlo, 0) and
+    // [nloc, xhi), the matrix lead rows [slo, 0) hold the +P entries of the plane below; the second sweep of the
+    // rows outside [st_lo, st_hi) needs the neighbours' once-relaxed planes and is left to the caller, for whom
+    // the once-relaxed iterate of the rows below k1_lo / from k1_hi on is written to v1out.
+    int64_t xlo, xhi, slo, st_lo, st_hi, k1_lo, k1_hi;
+    double* v1out;          // row-based, may be null (whole levels)
+    const double* zero;     // >= 3*S+1 stored zeros (the slack in front of a vector)
     int nx, ny, nz;
-    int ntx, nty, nseg, seglen;
+    int ntx, nty, seg0, seglen;     // this launch covers the plane segments seg0 .. seg0 + nitems/(ntx*nty) - 1
     unsigned nitems;
     double omega;
 };
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
     }
     if (id >= a.nitems) return;
     const unsigned ntile = (unsigned)(a.ntx * a.nty);
-    const int seg = (int)(id / ntile);
+    const int seg = a.seg0 + (int)(id / ntile);
     const unsigned t = id % ntile;
     const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
     const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
@@ -96,9 +103,9 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
         const uint64_t m = (uint64_t)(row + a.mlead);
         return a.vals + (size_t)(m / S) * (4 * S) + (size_t)(m % S);
     };
-    const double* const zx = a.x - 1;                     // zero slack in front of the vectors
-    const double* const zf = a.f - 1;
-    const double* const zm = mat(-1);                     // a zero lead row of the matrix (all four slots)
+    const double* const zx = a.zero;
+    const double* const zf = a.zero;
+    const double* const zm = a.zero;                      // stands for all four slots of a row (m + c*S)
 
     // registers.  plane k: +P diagonal, f, omega/diag, the second sweep's sum up to the +nx term, v1;
     // planes k+1 and k+2 (in flight): the matrix row and f; x of planes k .. k+3
@@ -121,30 +128,32 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int64_t r2 = rowof(c) + o2, r3 = rowof(c) + o3;
-            const bool ok2 = need2 && r2 >= 0 && r2 < a.nloc;
+            const bool ok2 = need2 && r2 >= a.slo && r2 < a.nloc;      // lead rows: upper entries only, diagonal 0
             const double* m = ok2 ? mat(r2) : zm;
             d2[c] = j2_ld<NT>(m, true, zm);
             p2[c] = j2_ld<NT>(m + S, true, zm);
             q2[c] = j2_ld<NT>(m + 2 * S, true, zm);
             s2[c] = j2_ld<NT>(m + 3 * S, true, zm);
-            f2[c] = j2_ld<NT>(a.f + r2, ok2, zf);
-            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= 0 && r3 < a.nloc, zx);
+            f2[c] = j2_ld<NT>(a.f + r2, ok2 && r2 >= 0, zf);
+            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= a.xlo && r3 < a.xhi, zx);
         }
 #pragma unroll
         for (int l = 0; l < LPW; ++l) {
             // x ring: the cell left of ex = 0 (lane 0) and right of ex = EX-1 (lane 63)
             const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o2;
-            const bool okh = need2 && (hl || hr) && hrow >= 0 && hrow < a.nloc;
-            hxv[l] = j2_ld<false>(a.x + hrow, okh, zx);
-            hxu[l] = j2_ld<false>((okh && hl ? mat(hrow) : zm) + S, true, zm);
+            const bool okx = need2 && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
+            const bool okh = okx && hl && hrow >= a.slo && hrow < a.nloc;
+            hxv[l] = j2_ld<false>(a.x + hrow, okx, zx);
+            hxu[l] = j2_ld<false>((okh ? mat(hrow) : zm) + S, true, zm);
         }
         // y ring: the line below ey = 0 (first wave) and above ey = EY-1 (last wave)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o2;
-            const bool okh = need2 && (wlo || whi) && hrow >= 0 && hrow < a.nloc;
-            hyv[r] = j2_ld<false>(a.x + hrow, okh, zx);
-            hyu[r] = j2_ld<false>((okh && wlo ? mat(hrow) : zm) + 2 * S, true, zm);
+            const bool okx = need2 && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
+            const bool okh = okx && wlo && hrow >= a.slo && hrow < a.nloc;
+            hyv[r] = j2_ld<false>(a.x + hrow, okx, zx);
+            hyu[r] = j2_ld<false>((okh ? mat(hrow) : zm) + 2 * S, true, zm);
         }
 
         const int sp = (k + 1) & 1;
@@ -169,8 +178,12 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
                 const int64_t r1 = rowof(c) + o1;
                 w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
                 sV1[iw] = w1[c];
-                if (k >= z0 && (inT >> c & 1u))
-                    a.out[r1 - a.P] = w0[c] + cf0[c] * (f0[c] - fma(s0[c], w1[c], ap0[c]));
+                if (inT >> c & 1u) {
+                    const int64_t r0 = r1 - a.P;
+                    if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi)
+                        a.out[r0] = w0[c] + cf0[c] * (f0[c] - fma(s0[c], w1[c], ap0[c]));
+                    if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
+                }
             }
         }
         __syncthreads();

@@ -87,6 +87,8 @@ def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode
                 h.set_params(mu, mu, bag.omega)
                 h.set_vector(hi, "f", f)
         info = par.level_info(hi)
+        if "fuse_min_rows" in tuning:           # the smoother really pairs sweeps on this slab
+            assert par.time_kernel("jacobi2", hi, 1) > 0.0
         assert not info["replicated"] and par.level_info(lo)["replicated"]
         assert info["n_local"] < info["n_global"]
         for h in (par, ser):

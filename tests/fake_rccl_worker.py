@@ -23,6 +23,7 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
     _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
     uid = buf.raw
     results, errors = [None] * world, []
+    tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("MG_TEST_TUNE", "").split(",") if kv}
 
     def rank_main(rank):
         try:
@@ -30,7 +31,7 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
                 h.set_tuning("overlap", overlap)
                 h.set_tuning("overlap_min_rows", 0)     # tiny grids: still take the overlapped sweep path
                 h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
-            h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm)
+            h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, **tune)
             info = h.level_info(hi)
             assert not info["replicated"] and info["n_local"] < info["n_global"]
             h.zero_vector(hi, "v")
@@ -60,7 +61,7 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
     assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
     assert not errors, errors
 
-    with DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu) as ser:
+    with DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, **tune) as ser:
         ser.zero_vector(hi, "v")
         res = ser.vcycle(hi, 3, residuals=True)
         want = ser.get_vector(hi, "v")

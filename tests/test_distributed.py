@@ -53,6 +53,18 @@ def test_slab_interior_is_strip_walked_while_the_halo_travels():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,mu,segments", [(2, 2, 0), (3, 3, 0), (4, 5, 0), (2, 4, 4), (3, 5, 5)])
+def test_paired_sweeps_on_slabs_match_single_handle(world, mu, segments):
+    """The two-sweep kernel on slabs (129^3 and 65^3 unknowns, both distributed): interior rows get both sweeps in
+    one pass, the slices holding a slab's first / last plane get their second sweep from the one-sweep kernel after
+    the once-relaxed boundary planes have been exchanged.  Bit-identical to the single-handle run, odd sweep
+    counts included.  With >= 4 plane segments per slab the pass is split so that both exchanges of a pair travel
+    behind interior segments (boundary segments first)."""
+    from tests.dist_workers import gpu_slab_worker
+    _spawn(gpu_slab_worker, world, 3, 2, 4, 8, mu, 0, "gen", {"fuse_min_rows": 0, "fuse_segments": segments})
+
+
+@pytest.mark.gpu
 def test_rccl_entry_points_on_one_rank():
     """Every RCCL call the slab transport makes (unique id by value, init, all-reduce, grouped
     broadcast, grouped send/recv, destroy), on a one-rank communicator -- all a 1-GPU box can run."""
@@ -61,9 +73,11 @@ def test_rccl_entry_points_on_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap", [(2, 3, 1, 3, 4, 0, 1), (4, 3, 1, 3, 4, 0, 1), (3, 2, 1, 3, 8, 1000, 1),
-                                                         (4, 3, 1, 3, 4, 0, 0), (2, 3, 2, 4, 8, 300000, 1)])
-def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi, c, rep, overlap):
+@pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap,tune", [
+    (2, 3, 1, 3, 4, 0, 1, ""), (4, 3, 1, 3, 4, 0, 1, ""), (3, 2, 1, 3, 8, 1000, 1, ""), (4, 3, 1, 3, 4, 0, 0, ""),
+    (2, 3, 2, 4, 8, 300000, 1, ""), (2, 3, 2, 4, 8, 0, 1, "fuse_min_rows=0"), (4, 3, 2, 4, 8, 300000, 0, "fuse_min_rows=0"),
+    (2, 3, 2, 4, 8, 0, 1, "fuse_min_rows=0,fuse_segments=4"), (4, 3, 2, 4, 8, 300000, 1, "fuse_min_rows=0,fuse_segments=4")])
+def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi, c, rep, overlap, tune):
     """The library's RCCL branch (not the callback transport): grouped send/recv on the communication stream,
     ordered by events against the boundary / interior sweeps, all-reduce, grouped broadcasts -- executed against
     an in-process stand-in for librccl (tests/fake_rccl) with one thread per rank on one GPU.  A real multi-GPU
@@ -75,7 +89,7 @@ def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi
     lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(lib):
         subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
-    env = dict(os.environ, MG_RCCL_LIBRARY=lib)
+    env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_TUNE=tune)
     out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), str(dim), str(lo),
                           str(hi), str(c), "2", str(rep), str(overlap)], env=env, capture_output=True, text=True,
                          timeout=600)
