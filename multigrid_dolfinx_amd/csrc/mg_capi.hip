@@ -175,7 +175,7 @@ struct mg_context {
     int dim = 2, nlev = 0, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;      // halo exchange overlapped with interior sweeps (world > 1)
-    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_vhalo = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     int overlap = 1;
     int64_t overlap_min_rows = (int64_t)1 << 22;
     std::vector<Level> L;
@@ -210,7 +210,6 @@ struct mg_context {
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
     int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
     int64_t fuse_min_rows = (int64_t)1 << 24;
-    int fuse_shape = 0;             // 0: 8 waves x 2 lines, 1: 16 waves x 1 line
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     DirectSolver direct;
@@ -674,19 +673,54 @@ bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = fal
     return ignore_size || L.nloc >= c->fuse_min_rows;
 }
 
-constexpr int kJ2Lines = 16;        // grid lines per tile of both launch shapes (8 waves x 2, 16 waves x 1)
+constexpr int kJ2Lines = 16;        // grid lines per tile (8 waves x 2)
 
-// Tiles per plane segment and the cut of the owned planes into segments: enough work items for ~16 rounds over
-// the CUs, segments no shorter than 32 planes (each pays 5 warm-up steps).
-void jacobi2_plan(const mg_context* c, const Level& L, int* ntx, int* nty, int* nseg, int* seglen) {
-    *ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
-    *nty = (L.g.ny + kJ2Lines - 3) / (kJ2Lines - 2);
-    const int64_t ntile = (int64_t)*ntx * *nty;
-    int n = c->fuse_segments;
-    if (n <= 0) n = (int)std::max<int64_t>(1, std::min<int64_t>((16 * 256 + ntile - 1) / ntile, L.g.nk / 32));
-    n = std::max(1, std::min(n, L.g.nk));
-    *seglen = (L.g.nk + n - 1) / n;
-    *nseg = (L.g.nk + *seglen - 1) / *seglen;
+// How a level's owned planes are cut into segments (one work item = one tile x one segment).  Segment 0 is
+// [0, zb), the last one [nk-zb, nk), the others cut the planes between into pieces of `seglen`.
+//   whole levels: equal pieces, their number chosen by a cost model -- rounds of 256 resident workgroups times
+//     (planes per piece + ~2.5 plane-times of warm-up) -- which is what measured best on 1025^3 (8 pieces);
+//   slabs: zb short (the planes whose once-relaxed values travel to the neighbours, rounded up to 8), so that the
+//     boundary work that the exchanges wait for is small, the interior cut by the same cost model.
+struct J2Plan { int ntx, nty, nseg, zb, seglen; };
+
+J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boundary_rows) {
+    J2Plan p{};
+    p.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
+    p.nty = (L.g.ny + kJ2Lines - 3) / (kJ2Lines - 2);
+    const int64_t ntile = (int64_t)p.ntx * p.nty;
+    const int nk = L.g.nk;
+    auto pieces = [&](int planes, int most) {
+        int best = 1;
+        double best_cost = 1e300;
+        for (int n = 1; n <= std::max(1, most); ++n) {
+            const double cost = (double)((ntile * n + 255) / 256) * ((planes + n - 1) / n + 2.5);
+            if (cost < best_cost) { best_cost = cost; best = n; }
+        }
+        return best;
+    };
+    if (slab) {
+        const int zb = (int)std::max<int64_t>(8, ((boundary_rows + L.g.plane - 1) / L.g.plane + 7) / 8 * 8);
+        if (nk >= 2 * zb + 8) {
+            const int inner = nk - 2 * zb;
+            int m = c->fuse_segments > 2 ? c->fuse_segments - 2 : pieces(inner, inner / 8);
+            m = std::max(1, std::min(m, inner));
+            p.zb = zb; p.seglen = (inner + m - 1) / m; p.nseg = 2 + (inner + p.seglen - 1) / p.seglen;
+            return p;
+        }
+        p.zb = nk; p.seglen = nk; p.nseg = 1;      // too thin to split: one segment, exchanges in sequence
+        return p;
+    }
+    int n = c->fuse_segments > 0 ? c->fuse_segments : pieces(nk, nk / 16);
+    n = std::max(1, std::min(n, nk));
+    if (n <= 2) {
+        p.zb = (nk + n - 1) / n; p.seglen = nk; p.nseg = n;
+    } else {
+        p.zb = std::max(1, nk / n);
+        const int inner = nk - 2 * p.zb;
+        p.seglen = (inner + n - 3) / (n - 2);
+        p.nseg = 2 + (inner + p.seglen - 1) / p.seglen;
+    }
+    return p;
 }
 
 template <int R, int NW, int LPW>
@@ -712,11 +746,13 @@ int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg) {
     return 0;
 }
 
-// out = two Jacobi sweeps applied to x, for the plane segments [seg_lo, seg_hi) (default: all)
+// out = two Jacobi sweeps applied to x, for `count` plane segments seg0, seg0 + stride, ... of `plan`
 // (slabs: the second sweep is stored for the rows [st_lo, st_hi) only and the once-relaxed iterate of the rows
 // within reach of the others goes to v1_rows, see smooth())
-int launch_jacobi2(mg_context* c, const Level& L, const double* x_rows, const double* f_rows, double* out_rows,
-                   int64_t st_lo = 0, int64_t st_hi = INT64_MAX, double* v1_rows = nullptr, int seg_lo = 0, int seg_hi = -1) {
+int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, int stride, int count, const double* x_rows,
+                   const double* f_rows, double* out_rows, int64_t st_lo = 0, int64_t st_hi = INT64_MAX,
+                   double* v1_rows = nullptr) {
+    if (count <= 0) return 0;
     J2Args a{};
     a.vals = L.dvals; a.x = x_rows; a.f = f_rows; a.out = out_rows;
     a.nloc = L.nloc; a.mlead = L.mlead; a.P = L.g.plane;
@@ -725,16 +761,13 @@ int launch_jacobi2(mg_context* c, const Level& L, const double* x_rows, const do
     a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.slo = -L.halo_lo;
     a.st_lo = st_lo; a.st_hi = st_hi; a.v1out = v1_rows;
     a.k1_lo = st_lo + L.g.plane + L.g.nx + 2; a.k1_hi = st_hi - L.g.plane - L.g.nx - 2;
-    int nseg = 0;
-    jacobi2_plan(c, L, &a.ntx, &a.nty, &nseg, &a.seglen);
-    if (seg_hi < 0) seg_hi = nseg;
-    if (seg_lo < 0 || seg_hi > nseg) return fail("bad segment range");
-    if (seg_hi <= seg_lo) return 0;
-    a.seg0 = seg_lo;
-    const int n = seg_hi - seg_lo;
-    if (L.R == 2) return c->fuse_shape ? launch_jacobi2_t<2, 16, 1>(c, a, n) : launch_jacobi2_t<2, 8, 2>(c, a, n);
-    if (L.R == 1) return c->fuse_shape ? launch_jacobi2_t<1, 16, 1>(c, a, n) : launch_jacobi2_t<1, 8, 2>(c, a, n);
-    return c->fuse_shape ? launch_jacobi2_t<4, 16, 1>(c, a, n) : launch_jacobi2_t<4, 8, 2>(c, a, n);
+    a.ntx = plan.ntx; a.nty = plan.nty; a.nseg = plan.nseg; a.zb = plan.zb; a.seglen = plan.seglen;
+    a.seg0 = seg0; a.seg_stride = stride;
+    const int n = count;
+    // 8 waves x 2 grid lines each (16 waves x 1 line measured slower and does not fit 128 registers)
+    if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n);
+    if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n);
+    return launch_jacobi2_t<4, 8, 2>(c, a, n);
 }
 
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
@@ -761,73 +794,56 @@ int smooth(mg_context* c, int level, int nw) {
     // form: exchange in-stream there
     const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream && L.nloc >= c->overlap_min_rows;
     const bool fused = fused_sweeps_ok(c, L) && (!dist || hi_begin > lo_end);
-    if (fused && dist && nw > 1) MG_TRY(vec_alloc(c, L, &L.sw));
-    int j2_nseg = 0;
-    if (fused) {
-        int ntx, nty, seglen;
-        jacobi2_plan(c, L, &ntx, &nty, &j2_nseg, &seglen);
-        // the first / last segment must hold every row whose once-relaxed value travels or whose second sweep waits
-        // for the neighbours (launch_jacobi2: k1_lo, k1_hi), else all segments go in one launch
-        const int64_t reach = L.g.plane + L.g.nx + 2;
-        if (dist && ((int64_t)seglen * L.g.plane < lo_end * S + reach ||
-                     (int64_t)(j2_nseg - 1) * seglen * L.g.plane > hi_begin * S - reach))
-            j2_nseg = 1;
+    J2Plan plan{};
+    if (fused && nw > 1) {
+        if (dist) MG_TRY(vec_alloc(c, L, &L.sw));
+        plan = jacobi2_plan(c, L, dist, lo_end * S + L.g.plane + L.g.nx + 2);
     }
-    bool vhalo_pending = false;         // an exchange of v's halos is in flight on the communication stream
     for (int s = 0; s < nw; ++s) {
         if (fused && s + 1 < nw) {
             if (!dist) {
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows));
-            } else if (overlap && j2_nseg >= 4) {
-                // both exchanges of a pair travel while interior plane segments are relaxed:
-                //   boundary segments -> [v1 planes travel | interior, first half] -> boundary slices' 2nd sweep
-                //   -> [v2 planes travel | interior, second half]; the next pair (or the exit) waits for the latter
-                const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
-                const int64_t st_lo = lo ? lo_end * S : 0, st_hi = hi ? hi_begin * S : INT64_MAX;
-                const int mid = 1 + (j2_nseg - 2) / 2;
-                if (vhalo_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, 0, 1));
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, j2_nseg - 1, j2_nseg));
-                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
-                MG_TRY(exchange_halo(c, L, L.sw, c->comm_stream));
-                HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, 1, mid));
-                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-                if (lo) MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
-                if (hi)
-                    MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
-                                      L.nslices - hi_begin));
-                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
-                MG_TRY(exchange_halo(c, L, L.v2, c->comm_stream));
-                HIP_TRY(hipEventRecord(c->ev_vhalo, c->comm_stream));
-                vhalo_pending = true;
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows, mid, j2_nseg - 1));
+                MG_TRY(launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows));
                 std::swap(L.v, L.v2);
                 ++s;
                 continue;
-            } else {
-                // the rows of the slices that hold the first / last owned plane need the neighbours' once-relaxed
-                // planes for their second sweep: the pass leaves them out and parks v1 around them in `sw`, whose
-                // halos are then exchanged like any iterate's, and the one-sweep kernel finishes those slices
-                const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
-                MG_TRY(launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows, lo ? lo_end * S : 0,
-                                      hi ? hi_begin * S : INT64_MAX, L.sw.rows));
-                MG_TRY(exchange_halo(c, L, L.sw));
+            }
+            // Slabs.  The rows of the slices that hold the first / last owned plane need the neighbours' once-relaxed
+            // planes for their second sweep: the pass leaves them out and parks v1 around them in `sw`, whose halos
+            // are then exchanged like any iterate's, and the one-sweep kernel finishes those slices.
+            const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
+            const int64_t st_lo = lo ? lo_end * S : 0, st_hi = hi ? hi_begin * S : INT64_MAX;
+            auto boundary_chain = [&](hipStream_t stream) -> int {
+                MG_TRY(exchange_halo(c, L, L.sw, stream));
                 if (lo) MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
                 if (hi)
                     MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
                                       L.nslices - hi_begin));
+                MG_TRY(exchange_halo(c, L, L.v2, stream));
+                return 0;
+            };
+            if (overlap && plan.nseg >= 3) {
+                // the two boundary segments and everything that waits for the neighbours run on the communication
+                // stream, the interior segments beside them on the main stream; the pair ends when both have
+                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+                std::swap(c->stream, c->comm_stream);
+                int rc = launch_jacobi2(c, L, plan, 0, plan.nseg - 1, 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows);
+                std::swap(c->stream, c->comm_stream);
+                MG_TRY(rc);
+                MG_TRY(launch_jacobi2(c, L, plan, 1, 1, plan.nseg - 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+                std::swap(c->stream, c->comm_stream);
+                rc = boundary_chain(c->stream);
+                std::swap(c->stream, c->comm_stream);
+                MG_TRY(rc);
+                HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+            } else {
+                MG_TRY(launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+                MG_TRY(boundary_chain(c->stream));
             }
             std::swap(L.v, L.v2);
-            MG_TRY(exchange_halo(c, L, L.v));
             ++s;
             continue;
-        }
-        if (vhalo_pending) {
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
-            vhalo_pending = false;
         }
         if (!overlap) {
             MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr));
@@ -848,7 +864,6 @@ int smooth(mg_context* c, int level, int nw) {
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
         std::swap(L.v, L.v2);
     }
-    if (vhalo_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vhalo, 0));
     return 0;
 }
 
@@ -1428,7 +1443,6 @@ int mg_create(int n_levels, int dim, int device, mg_handle* out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_vhalo, hipEventDisableTiming));
     MG_TRY(dev_alloc(c, &c->partials, 2 * kMaxParts));
     MG_TRY(dev_alloc(c, &c->scalars, 8));
     MG_TRY(dev_alloc(c, &c->done, 1));
@@ -1460,7 +1474,6 @@ int mg_destroy(mg_handle c) {
     if (c->comm.nccl) g_rccl.CommDestroy(c->comm.nccl);
     if (c->ev_boundary) (void)hipEventDestroy(c->ev_boundary);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
-    if (c->ev_vhalo) (void)hipEventDestroy(c->ev_vhalo);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1610,9 +1623,6 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_sweeps = value != 0;
     } else if (k == "fuse_min_rows") {
         c->fuse_min_rows = value;
-    } else if (k == "fuse_shape") {
-        if (value != 0 && value != 1) return fail("fuse_shape must be 0 or 1");
-        c->fuse_shape = (int)value;
     } else if (k == "fuse_nontemporal") {
         c->fuse_nontemporal = value != 0;
     } else if (k == "fuse_segments") {
@@ -2110,9 +2120,11 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
     auto once = [&]() -> int {
         if (k == "jacobi") return launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
         // "jacobi2": only where mg_smooth itself pairs sweeps on this level; "jacobi2!": wherever the kernel applies
-        if (k == "jacobi2" || k == "jacobi2!")
-            return fused_sweeps_ok(c, L, k == "jacobi2!") ? launch_jacobi2(c, L, L.v.rows, L.f.rows, L.v2.rows)
-                                                           : fail("level does not use the two-sweep kernel");
+        if (k == "jacobi2" || k == "jacobi2!") {
+            if (!fused_sweeps_ok(c, L, k == "jacobi2!")) return fail("level does not use the two-sweep kernel");
+            const J2Plan plan = jacobi2_plan(c, L, false, 0);
+            return launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows);
+        }
         if (k == "residual") return residual(c, level);
         if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");
         if (k == "prolong") return level > 0 ? prolong(c, level, 1) : fail("level 0");

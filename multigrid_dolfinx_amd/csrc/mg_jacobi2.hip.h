@@ -18,7 +18,7 @@
 // space (cell (ex, ey, k) <-> row k*P + (ty0+ey)*nx + tx0+ex, whether or not that wraps around a grid line),
 // which is exactly what the one-sweep kernel computes, with the same fma order and the same IEEE division:
 // results are bit-identical to two sdia_jacobi launches.  Tiles are independent (out != x), the plane range
-// is cut into `nseg` segments to have >> 256 work items, each paying 5 warm-up steps.
+// is cut into segments to have >> 256 work items, each paying one round of warm-up loads and two extra steps.
 #pragma once
 #include "mg_kernels.hip.h"
 
@@ -38,7 +38,9 @@ struct J2Args {
     double* v1out;          // row-based, may be null (whole levels)
     const double* zero;     // >= 3*S+1 stored zeros (the slack in front of a vector)
     int nx, ny, nz;
-    int ntx, nty, seg0, seglen;     // this launch covers the plane segments seg0 .. seg0 + nitems/(ntx*nty) - 1
+    // plane segments: 0 = [0, zb), nseg-1 = [nz-zb, nz), the others cut [zb, nz-zb) into pieces of seglen planes;
+    // this launch covers the segments seg0, seg0 + seg_stride, ... (nitems / (ntx*nty) of them)
+    int ntx, nty, nseg, zb, seglen, seg0, seg_stride;
     unsigned nitems;
     double omega;
 };
@@ -76,10 +78,14 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
     }
     if (id >= a.nitems) return;
     const unsigned ntile = (unsigned)(a.ntx * a.nty);
-    const int seg = a.seg0 + (int)(id / ntile);
+    const int seg = a.seg0 + (int)(id / ntile) * a.seg_stride;
     const unsigned t = id % ntile;
     const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
-    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    int z0, z1;
+    if (seg == 0) { z0 = 0; z1 = min(a.zb, a.nz); }
+    else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
+    else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
+    if (z1 <= z0) return;
     const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;      // grid position of cell (0, 0)
 
     // cell c = 2*l + r of this thread: ex = lane + 64 r, ey = wave*LPW + l; everything else is an offset from cell 0
@@ -115,33 +121,29 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
     double va[NC], vb[NC], vc[NC], vd[NC], w1[NC];
     double hxv[LPW], hxu[LPW], hyv[2], hyu[2];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        s0[c] = f0[c] = cf0[c] = ap0[c] = w0[c] = 0.0;
-        d1[c] = p1[c] = q1[c] = s1[c] = f1[c] = 0.0;
-        va[c] = vb[c] = vc[c] = w1[c] = 0.0;
-    }
+    for (int c = 0; c < NC; ++c) f0[c] = cf0[c] = ap0[c] = w0[c] = w1[c] = 0.0;
 
-    for (int k = z0 - 5; k < z1; ++k) {
-        // ---- issue the loads of plane k+2 (matrix, f, ring) and of plane k+3 (x) ----
-        const int64_t o2 = (int64_t)(k + 2) * a.P, o3 = o2 + a.P;
-        const bool need2 = k + 2 >= z0 - 2 && k + 2 <= z1, need3 = k + 3 <= z1 + 1;
+    // the matrix row, f and the ring (x and the diagonals its sweep needs) of one plane
+    // (`on` false: a plane past the segment that no step uses -- every lane reads the stored zero)
+    auto load_plane = [&](const int plane, const bool on, double (&d)[NC], double (&p)[NC], double (&q)[NC],
+                          double (&sd)[NC], double (&fr)[NC]) {
+        const int64_t o = (int64_t)plane * a.P;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int64_t r2 = rowof(c) + o2, r3 = rowof(c) + o3;
-            const bool ok2 = need2 && r2 >= a.slo && r2 < a.nloc;      // lead rows: upper entries only, diagonal 0
-            const double* m = ok2 ? mat(r2) : zm;
-            d2[c] = j2_ld<NT>(m, true, zm);
-            p2[c] = j2_ld<NT>(m + S, true, zm);
-            q2[c] = j2_ld<NT>(m + 2 * S, true, zm);
-            s2[c] = j2_ld<NT>(m + 3 * S, true, zm);
-            f2[c] = j2_ld<NT>(a.f + r2, ok2 && r2 >= 0, zf);
-            vd[c] = j2_ld<false>(a.x + r3, need3 && r3 >= a.xlo && r3 < a.xhi, zx);
+            const int64_t r = rowof(c) + o;
+            const bool ok = on && r >= a.slo && r < a.nloc;         // lead rows: upper entries only, diagonal 0
+            const double* m = ok ? mat(r) : zm;
+            d[c] = j2_ld<NT>(m, true, zm);
+            p[c] = j2_ld<NT>(m + S, true, zm);
+            q[c] = j2_ld<NT>(m + 2 * S, true, zm);
+            sd[c] = j2_ld<NT>(m + 3 * S, true, zm);
+            fr[c] = j2_ld<NT>(a.f + r, ok && r >= 0, zf);
         }
 #pragma unroll
         for (int l = 0; l < LPW; ++l) {
             // x ring: the cell left of ex = 0 (lane 0) and right of ex = EX-1 (lane 63)
-            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o2;
-            const bool okx = need2 && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
+            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o;
+            const bool okx = on && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
             const bool okh = okx && hl && hrow >= a.slo && hrow < a.nloc;
             hxv[l] = j2_ld<false>(a.x + hrow, okx, zx);
             hxu[l] = j2_ld<false>((okh ? mat(hrow) : zm) + S, true, zm);
@@ -149,19 +151,74 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
         // y ring: the line below ey = 0 (first wave) and above ey = EY-1 (last wave)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o2;
-            const bool okx = need2 && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
+            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o;
+            const bool okx = on && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
             const bool okh = okx && wlo && hrow >= a.slo && hrow < a.nloc;
             hyv[r] = j2_ld<false>(a.x + hrow, okx, zx);
             hyu[r] = j2_ld<false>((okh ? mat(hrow) : zm) + 2 * S, true, zm);
         }
+    };
+    auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
+        const int64_t o = (int64_t)plane * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r = rowof(c) + o;
+            v[c] = j2_ld<false>(a.x + r, on && r >= a.xlo && r < a.xhi, zx);
+        }
+    };
+    // LDS image of one plane: x with its ring, the +1 / +nx diagonals (slot = plane parity) with theirs
+    auto park = [&](const int slot, const double (&v)[NC], const double (&p)[NC], const double (&q)[NC]) {
+        double* const u1s = sU1 + slot * (EY * PV) - PV;
+        double* const u2s = sU2 + slot * ((EY + 1) * EX) + EX;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iv = lvof(c), iw = lwof(c);
+            sV0[iv] = v[c];
+            u1s[iv] = p[c];
+            u2s[iw] = q[c];
+        }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            const int rowv = (ey0 + l + 1) * PV;
+            if (hl) { sV0[rowv] = hxv[l]; u1s[rowv] = hxu[l]; }
+            if (hr) sV0[rowv + EX + 1] = hxv[l];
+        }
+        if (wlo) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; u2s[lane + 64 * r - EX] = hyu[r]; }
+        } else if (whi) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
+        }
+    };
+
+    // ---- warm-up: everything the first step (k = z0-2) finds in place, in one round of loads ----
+    load_plane(z0 - 1, true, d1, p1, q1, s1, f1);
+    load_x(z0 - 2, true, va);
+    load_x(z0 - 1, true, vb);
+    load_x(z0, true, vc);
+    {
+        const int64_t o = (int64_t)(z0 - 2) * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r = rowof(c) + o;
+            s0[c] = j2_ld<NT>((r >= a.slo && r < a.nloc ? mat(r) : zm) + 3 * S, true, zm);
+        }
+    }
+    park((z0 - 1) & 1, vb, p1, q1);
+    __syncthreads();
+
+    for (int k = z0 - 2; k < z1; ++k) {
+        // ---- issue the loads of plane k+2 (matrix, f, ring) and of plane k+3 (x) ----
+        load_plane(k + 2, k + 2 <= z1, d2, p2, q2, s2, f2);
+        load_x(k + 3, k + 3 <= z1 + 1, vd);
 
         const int sp = (k + 1) & 1;
         const double* const u1p = sU1 + sp * (EY * PV) - PV;          // indexed like sV0
         const double* const u2p = sU2 + sp * ((EY + 1) * EX) + EX;    // indexed like sV1
         // ---- A: first sweep on plane k+1; the second sweep of plane k gets its last (+P) term ----
-        if (k >= z0 - 2) {
-            const int64_t o1 = o2 - a.P;
+        {
+            const int64_t o1 = (int64_t)(k + 1) * a.P;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int iv = lvof(c), iw = lwof(c);
@@ -205,31 +262,7 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2(J2Args a) {
             }
         }
         // ---- C: park plane k+2 (x arrived a step ago, matrix and ring just now); rotate ----
-        if (k >= z0 - 3) {
-            const int sc = k & 1;
-            double* const u1s = sU1 + sc * (EY * PV) - PV;
-            double* const u2s = sU2 + sc * ((EY + 1) * EX) + EX;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int iv = lvof(c), iw = lwof(c);
-                sV0[iv] = vc[c];
-                u1s[iv] = p2[c];
-                u2s[iw] = q2[c];
-            }
-#pragma unroll
-            for (int l = 0; l < LPW; ++l) {
-                const int rowv = (ey0 + l + 1) * PV;
-                if (hl) { sV0[rowv] = hxv[l]; u1s[rowv] = hxu[l]; }
-                if (hr) sV0[rowv + EX + 1] = hxv[l];
-            }
-            if (wlo) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; u2s[lane + 64 * r - EX] = hyu[r]; }
-            } else if (whi) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
-            }
-        }
+        park(k & 1, vc, p2, q2);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const double diag = d1[c] != 0.0 ? d1[c] : 1.0;

@@ -776,8 +776,8 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3, fuse_shape=1),
-                dict(fuse_segments=5, fuse_nontemporal=1), dict(rows_per_lane=1), dict(rows_per_lane=4, fuse_shape=1)]
+    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3),
+                dict(fuse_segments=5, fuse_nontemporal=1), dict(rows_per_lane=1), dict(rows_per_lane=4, fuse_segments=2)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}

@@ -14,10 +14,9 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=2, mu2=2) as dev:
     out["rows"] = n
     out["jacobi_ms"] = dev.time_kernel("jacobi", hi, reps)
     print(out, flush=True)
-    for shape in (0, 1):
-        for seg in (0, 4, 8, 12, 16, 24):
-            for nt in (1, 0):
-                dev.set_tuning("fuse_shape", shape)
+    for shape in (0,):
+        for seg in ([int(a) for a in sys.argv[3:]] or (0, 1, 3, 4, 6, 8, 11, 13, 16)):
+            for nt in (0,):
                 dev.set_tuning("fuse_segments", seg)
                 dev.set_tuning("fuse_nontemporal", nt)
                 ms = dev.time_kernel("jacobi2!", hi, reps)
