@@ -724,7 +724,7 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
 }
 
 template <int R, int NW, int LPW>
-int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg) {
+int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     static_assert(NW * LPW == kJ2Lines, "tile height");
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
     if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
@@ -733,15 +733,14 @@ int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg) {
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;      // whole groups of 8 XCDs x 32 items
     constexpr size_t lds = j2_lds_bytes<NW, LPW>();
     static bool attr_set = false;
-    auto* kern_nt = sdia_jacobi2<R, NW, LPW, true>;
-    auto* kern = sdia_jacobi2<R, NW, LPW, false>;
+    void (*const kern[4])(J2Args) = {sdia_jacobi2<R, NW, LPW, false>, sdia_jacobi2<R, NW, LPW, true>,
+                                     sdia_jacobi2_finest<R, NW, LPW, false>, sdia_jacobi2_finest<R, NW, LPW, true>};
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (auto* k : kern)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (c->fuse_nontemporal) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
-    else hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
+    hipLaunchKernelGGL(kern[(finest ? 2 : 0) + (c->fuse_nontemporal ? 1 : 0)], dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -765,9 +764,10 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     a.seg0 = seg0; a.seg_stride = stride;
     const int n = count;
     // 8 waves x 2 grid lines each (16 waves x 1 line measured slower and does not fit 128 registers)
-    if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n);
-    if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n);
-    return launch_jacobi2_t<4, 8, 2>(c, a, n);
+    const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
+    if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
+    if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n, finest);
+    return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
 }
 
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
