@@ -151,6 +151,11 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "overlap"            halo exchange on the communication stream behind the interior sweep (1)
  *     "overlap_min_rows"   ... only on levels with at least this many owned rows (4194304)
  *     "fuse_restrict"      residual evaluated at the coarse nodes only when injecting (1)
+ *     "fuse_sweeps"        Jacobi sweeps in pairs, two per pass over the matrix, on 3-D 7-point levels in
+ *                          symmetric diagonal storage (1); bit-identical to single sweeps
+ *     "fuse_min_rows"      ... only on levels with at least this many owned rows (16777216)
+ *     "fuse_segments"      plane segments per tile of that pass, 0 = chosen by the cost model (0)
+ *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
  *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)
@@ -213,8 +218,9 @@ int mg_fmg(mg_handle h, int top_level, int mu0, double tol, int max_cycles, doub
 /* ---- measurement -----------------------------------------------------------------------------
  * mg_time_kernel: average duration in milliseconds of `reps` back-to-back launches of
  * one kernel of the path on `level`, measured with HIP events on the handle's own
- * stream ("jacobi", "residual", "restrict", "prolong", "norm2").  Used by bench.py for
- * the roofline figure.  mg_sync waits for the handle's stream. */
+ * stream ("jacobi", "residual", "restrict", "prolong", "norm2"; "jacobi2" = the two-sweep pass, an
+ * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies).
+ * Used by bench.py for the roofline figure.  mg_sync waits for the handle's stream. */
 int mg_time_kernel(mg_handle h, const char* kernel, int level, int reps, double* avg_ms);
 int mg_sync(mg_handle h);
 /* bytes of device memory held by the handle */
