@@ -143,6 +143,7 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "offset_codes"       0 keeps int32 column indices (1)
  *     "symmetric_storage"  0 keeps lower entries even for bit-for-bit symmetric matrices (1)
  *     "require_diagonal"   0 accepts operators without a diagonal, e.g. D^-1 R for mg_smooth_split (1)
+ *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 7-point levels (1)
  *   any time:
  *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)
  *     "strip_slices"       slices per XCD strip, 0 = chunked map only (64)
@@ -156,6 +157,8 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "fuse_min_rows"      ... only on levels with at least this many owned rows (16777216)
  *     "fuse_segments"      plane segments per tile of that pass, 0 = chosen by the cost model (0)
  *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
+ *     "fuse_classes"       that pass reads one class byte per row instead of the 32-byte row where the level has
+ *                          row classes (1); bit-identical either way
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
  *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)
@@ -167,6 +170,10 @@ int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, i
                   int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated,
                   int* offset_codes /* 0 = int32 columns; > 0 = offset codes (number of distinct
                                        offsets); < 0 = symmetric diagonal storage (-stored diagonals) */);
+/* Number of distinct stored rows (the all-zero row included) when the level's symmetric diagonal storage also
+ * carries one class byte per row for the two-sweep pass, 0 when it does not (more than 255 distinct rows, another
+ * format, "row_classes" 0).  No reference counterpart: storage detail of jacobiRelaxation (multigrid.py:223-228). */
+int mg_level_row_classes(mg_handle h, int level, int* classes);
 
 /* ---- vectors ---------------------------------------------------------------------------
  * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the

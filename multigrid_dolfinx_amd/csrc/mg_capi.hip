@@ -141,6 +141,10 @@ struct Level {
     int wu = 0;
     int up[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t mlead = 0, mslices = 0;
+    // row classes of the symmetric diagonal storage (mg_jacobi2.hip.h): one byte per stored row + a 256 x 4 table
+    unsigned char* cls = nullptr;
+    double* ctab = nullptr;
+    int ncls = 0;
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
     DVector sw;                             // once-relaxed boundary planes of a slab (paired sweeps, world > 1)
@@ -208,10 +212,12 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    int use_classes = 1;            // one class byte per row where a level has <= 255 distinct rows (two-sweep pass)
     int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
     int64_t fuse_min_rows = (int64_t)1 << 24;
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
+    int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -377,6 +383,9 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * (WAVE * L.R));
     dev_free(c, L.offsets, 256);
     dev_free(c, L.dvals, (size_t)L.mslices * (L.wu > 0 ? L.wu : 1) * (WAVE * L.R));
+    dev_free(c, L.cls, (size_t)L.mslices * (WAVE * L.R));
+    dev_free(c, L.ctab, 256 * 4);
+    L.ncls = 0;
     L.coded = false;
     L.rb_ok = false;
     L.sdia = false;
@@ -723,6 +732,27 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     return p;
 }
 
+template <int NW, int LPW>
+int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
+    static_assert(NW * LPW == kJ2Lines, "tile height");
+    const int64_t items = (int64_t)a.ntx * a.nty * nseg;
+    if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
+    J2Args b = a;
+    b.nitems = (unsigned)items;
+    const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
+    constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
+    static bool attr_set = false;
+    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
+    if (!attr_set) {
+        for (auto* k : kern)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int R, int NW, int LPW>
 int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     static_assert(NW * LPW == kJ2Lines, "tile height");
@@ -765,6 +795,10 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     const int n = count;
     // 8 waves x 2 grid lines each (16 waves x 1 line measured slower and does not fit 128 registers)
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
+    if (L.cls && c->fuse_classes) {
+        a.cls = L.cls; a.ctab = L.ctab;
+        return launch_jacobi2c_t<8, 2>(c, a, n, finest);
+    }
     if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
     if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n, finest);
     return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
@@ -1308,6 +1342,58 @@ int encode_level(mg_context* c, Level& L) {
     return 0;
 }
 
+// Row classes for the two-sweep pass (mg_jacobi2.hip.h, "row classes"): a dictionary of the level's distinct stored
+// rows, built and verified on the device; levels with more than 255 distinct non-zero rows go without.
+int build_row_classes(mg_context* c, Level& L) {
+    if (!c->use_classes || !L.sdia || L.wu != 4) return 0;
+    const int64_t S = (int64_t)WAVE * L.R, mrows = L.mslices * S;
+    // scratch: hash tags | slot values | count, flag, slot_class[CLS_SLOTS]
+    struct Scratch {
+        char* p = nullptr;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } scratch;
+    const size_t tag_bytes = CLS_SLOTS * sizeof(unsigned long long), val_bytes = (size_t)CLS_SLOTS * 4 * sizeof(double);
+    const size_t int_bytes = (2 + CLS_SLOTS) * sizeof(int);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch.p), tag_bytes + val_bytes + int_bytes));
+    HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + val_bytes + int_bytes, c->stream));
+    struct { unsigned long long* p; } tags{reinterpret_cast<unsigned long long*>(scratch.p)};
+    struct { double* p; } svals{reinterpret_cast<double*>(scratch.p + tag_bytes)};
+    struct { int* p; } ints{reinterpret_cast<int*>(scratch.p + tag_bytes + val_bytes)};
+    unsigned char* cls = nullptr;
+    double* ctab = nullptr;
+    MG_TRY(dev_alloc(c, &cls, (size_t)mrows));
+    MG_TRY(dev_alloc(c, &ctab, 256 * 4));
+    ClsArgs a{};
+    a.dvals = L.dvals; a.mrows = mrows; a.tags = tags.p; a.svals = svals.p; a.count = ints.p; a.flag = ints.p + 1;
+    a.slot_class = ints.p + 2; a.ctab = ctab; a.cls = cls;
+    const dim3 grid(blocks_for(mrows, 256)), blk(256);
+    int h[2] = {0, 0};
+    int rc = [&]() -> int {
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(cls_insert<64>, grid, blk, 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(cls_insert<128>, grid, blk, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(cls_insert<256>, grid, blk, 0, c->stream, a); break;
+        }
+        hipLaunchKernelGGL(cls_assign, dim3(1), dim3(64), 0, c->stream, a);
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(cls_encode<64>, grid, blk, 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(cls_encode<128>, grid, blk, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(cls_encode<256>, grid, blk, 0, c->stream, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, ints.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass
+        dev_free(c, cls, (size_t)mrows);
+        dev_free(c, ctab, 256 * 4);
+        return rc;
+    }
+    L.cls = cls; L.ctab = ctab; L.ncls = h[0] + 1;
+    return 0;
+}
+
 // Symmetric diagonal storage: possible when the level is offset-coded, its offsets come in +/- pairs
 // and every lower entry equals its transposed partner bit for bit (mg_kernels.hip.h, sdia_*).
 // The coarsest level keeps the coded form (the direct solver reads it).
@@ -1362,7 +1448,7 @@ int repack_sdia(mg_context* c, Level& L, int level) {
     // padded template slots (wu < wu_t) hold zeros and offset 0: they add 0 * x[row]
     dev_free(c, L.vals, (size_t)L.nslices * L.W * S);
     dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * S);
-    return 0;
+    return build_row_classes(c, L);
 }
 
 int finish_level(mg_context* c, Level& L) {
@@ -1604,6 +1690,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         for (auto& L : c->L)
             if (L.set) return fail("symmetric_storage must be chosen before level set-up");
         c->use_sdia = value != 0;
+    } else if (k == "row_classes") {
+        for (auto& L : c->L)
+            if (L.set) return fail("row_classes must be chosen before level set-up");
+        c->use_classes = value != 0;
     } else if (k == "strip_slices") {
         if (value < 0 || value > 4096 || value % 4) return fail("strip_slices must be a multiple of 4 in 0..4096");
         c->strip_slices = (int)value;
@@ -1623,6 +1713,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_sweeps = value != 0;
     } else if (k == "fuse_min_rows") {
         c->fuse_min_rows = value;
+    } else if (k == "fuse_classes") {
+        c->fuse_classes = value != 0;
     } else if (k == "fuse_nontemporal") {
         c->fuse_nontemporal = value != 0;
     } else if (k == "fuse_segments") {
@@ -1861,6 +1953,13 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
     if (ell_width) *ell_width = L.W;
     if (replicated) *replicated = L.replicated ? 1 : 0;
     if (offset_codes) *offset_codes = L.sdia ? -L.wu : (L.coded ? L.ntable : 0);
+    return 0;
+}
+
+int mg_level_row_classes(mg_handle c, int level, int* classes) {
+    MG_TRY(check_level(c, level));
+    if (!classes) return fail("bad arguments");
+    *classes = c->L[level].cls ? c->L[level].ncls : 0;
     return 0;
 }
 

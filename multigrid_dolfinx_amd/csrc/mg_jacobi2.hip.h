@@ -37,6 +37,9 @@ struct J2Args {
     int64_t xlo, xhi, slo, st_lo, st_hi, k1_lo, k1_hi;
     double* v1out;          // row-based, may be null (whole levels)
     const double* zero;     // >= 3*S+1 stored zeros (the slack in front of a vector)
+    // row classes (sdia_jacobi2c): cls[row + mlead] indexes ctab[class][4] = (diagonal, +1, +nx, +P entries)
+    const unsigned char* cls;
+    const double* ctab;
     int nx, ny, nz;
     // plane segments: 0 = [0, zb), nseg-1 = [nz-zb, nz), the others cut [zb, nz-zb) into pieces of seglen planes;
     // this launch covers the segments seg0, seg0 + seg_stride, ... (nitems / (ntx*nty) of them)
@@ -273,6 +276,327 @@ __device__ __forceinline__ void j2_body(const J2Args& a) {
         }
         __syncthreads();
     }
+}
+
+// ---- row classes ------------------------------------------------------------------------------
+// On the meshes this path is built for (uniform grids, constant coefficients) the rows of a level's matrix take
+// only a handful of distinct values: the interior stencil, its variants next to a Dirichlet boundary, the
+// identity rows.  When the stored rows (diagonal, +1, +nx, +P entry; the lower entries are those of other rows)
+// take at most 255 distinct non-zero values BIT FOR BIT, the two-sweep pass reads one byte per row -- its class --
+// instead of 32 bytes of matrix, and looks the entries up in a 256 x 4 table kept in LDS: 25 instead of 56 bytes
+// per row and pair of sweeps, with exactly the same arithmetic on exactly the same numbers.  The dictionary is
+// built on the device (hash insert, compaction, encode + bitwise verification); a level with more distinct rows
+// simply keeps the plain pass.
+constexpr int CLS_SLOTS = 4096;
+
+struct ClsArgs {
+    const double* dvals;            // symmetric diagonal storage, WU = 4
+    int64_t mrows;                  // rows stored (lead rows included)
+    unsigned long long* tags;       // CLS_SLOTS hash tags, 0 = free
+    double* svals;                  // CLS_SLOTS x 4
+    int* count;                     // distinct non-zero rows seen
+    int* slot_class;                // CLS_SLOTS
+    double* ctab;                   // 256 x 4
+    unsigned char* cls;             // mrows
+    int* flag;                      // set when a row does not match its dictionary entry
+};
+
+__device__ __forceinline__ unsigned long long cls_mix(unsigned long long x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+
+template <int S> __device__ __forceinline__ void cls_row(const ClsArgs& a, int64_t m, unsigned long long (&b)[4]) {
+    const size_t base = (size_t)(m / S) * (4 * S) + (size_t)(m % S);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = (unsigned long long)__double_as_longlong(a.dvals[base + (size_t)c * S]);
+}
+
+__device__ __forceinline__ unsigned long long cls_hash(const unsigned long long (&b)[4]) {
+    unsigned long long h = cls_mix(b[0] + 0x9e3779b97f4a7c15ull);
+    h = cls_mix(h ^ (b[1] + 0x3c6ef372fe94f82bull));
+    h = cls_mix(h ^ (b[2] + 0xdaa66d2c7ddf743full));
+    h = cls_mix(h ^ (b[3] + 0x78dde6e5fd29f054ull));
+    return h ? h : 1ull;
+}
+
+template <int S>
+__global__ void cls_insert(ClsArgs a) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.mrows) return;
+    unsigned long long b[4];
+    cls_row<S>(a, m, b);
+    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) return;          // class 0: the all-zero row
+    const unsigned long long h = cls_hash(b);
+    unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+    for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+        if (*(volatile int*)a.count > 255) return;             // too many distinct rows: the caller gives up
+        const unsigned long long old = atomicCAS(a.tags + s, 0ull, h);
+        if (old == 0ull) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a.svals[4 * s + c] = __longlong_as_double((long long)b[c]);
+            atomicAdd(a.count, 1);
+            return;
+        }
+        if (old == h) return;
+        s = (s + 1) & (CLS_SLOTS - 1);
+    }
+}
+
+// one thread: classes 1, 2, ... in slot order (deterministic for a given matrix)
+__global__ void cls_assign(ClsArgs a) {
+    if (blockIdx.x || threadIdx.x) return;
+    for (int c = 0; c < 4; ++c) a.ctab[c] = 0.0;
+    int id = 1;
+    for (int s = 0; s < CLS_SLOTS; ++s) {
+        a.slot_class[s] = 0;
+        if (a.tags[s] && id < 256) {
+            a.slot_class[s] = id;
+            for (int c = 0; c < 4; ++c) a.ctab[4 * id + c] = a.svals[4 * s + c];
+            ++id;
+        }
+    }
+    for (; id < 256; ++id)
+        for (int c = 0; c < 4; ++c) a.ctab[4 * id + c] = 0.0;
+}
+
+template <int S>
+__global__ void cls_encode(ClsArgs a) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.mrows) return;
+    unsigned long long b[4];
+    cls_row<S>(a, m, b);
+    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) { a.cls[m] = 0; return; }
+    const unsigned long long h = cls_hash(b);
+    unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+    for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+        const unsigned long long t = a.tags[s];
+        if (t == h) {
+            bool same = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) same = same && (unsigned long long)__double_as_longlong(a.svals[4 * s + c]) == b[c];
+            if (!same || a.slot_class[s] == 0) atomicExch(a.flag, 1);       // hash collision / overflow: no classes
+            a.cls[m] = (unsigned char)a.slot_class[s];
+            return;
+        }
+        if (t == 0ull) break;
+        s = (s + 1) & (CLS_SLOTS - 1);
+    }
+    atomicExch(a.flag, 1);
+    a.cls[m] = 0;
+}
+
+// ---- the two-sweep pass on class-coded rows ----------------------------------------------------
+// Same march, same arithmetic as j2_body; per cell and step it loads one class byte, f and x (17 bytes instead of
+// 48) and keeps classes where j2_body keeps matrix entries: the row's own entries and omega/diag come from the LDS
+// table (sT, sCF: one IEEE division per class and workgroup instead of two per cell and step), the neighbours'
+// +1 / +nx entries through the plane image of the classes (sC).
+template <int NW, int LPW> constexpr size_t j2c_lds_bytes() {
+    constexpr int EY = NW * LPW, PV = J2_EX + 2;
+    return sizeof(double) * (256 * 4 + 256 + (size_t)(EY + 2) * PV + (size_t)EY * J2_EX) + 2 * (size_t)(EY + 2) * PV;
+}
+
+template <int NW, int LPW>
+__device__ __forceinline__ void j2c_body(const J2Args& a) {
+    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
+    extern __shared__ double j2_smem[];
+    double* const sT = j2_smem;                           // 256 x 4    entries of the row classes
+    double* const sCF = sT + 256 * 4;                     // 256        omega / diagonal
+    double* const sV0 = sCF + 256;                        // (EY+2) x PV   x of one plane, origin (-1,-1)
+    double* const sV1 = sV0 + (EY + 2) * PV;              // EY x EX       once-relaxed iterate of one plane
+    unsigned char* const sC = reinterpret_cast<unsigned char*>(sV1 + EY * EX);   // 2 x (EY+2) x PV classes, like sV0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+        id = ((j >> 5) * 8u + xcd) * 32u + (j & 31u);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = a.seg0 + (int)(id / ntile) * a.seg_stride;
+    const unsigned t = id % ntile;
+    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
+    int z0, z1;
+    if (seg == 0) { z0 = 0; z1 = min(a.zb, a.nz); }
+    else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
+    else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
+    if (z1 <= z0) return;
+    const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;
+
+    for (int i = threadIdx.x; i < 256 * 4; i += NW * WAVE) sT[i] = a.ctab[i];
+    for (int i = threadIdx.x; i < 256; i += NW * WAVE) {
+        const double d = a.ctab[4 * i];
+        sCF[i] = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+    }
+
+    const int ey0 = wave * LPW;
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
+    const int lv0 = (ey0 + 1) * PV + lane + 1;
+    const int lw0 = ey0 * EX + lane;
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
+    auto lvof = [&](int c) -> int { return lv0 + (c >> 1) * PV + 64 * (c & 1); };
+    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
+    unsigned inT = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
+        if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
+    }
+    const bool hl = lane == 0, hr = lane == 63;
+    const bool wlo = wave == 0, whi = wave == NW - 1;
+    const unsigned char* const zc = reinterpret_cast<const unsigned char*>(a.zero);
+    const unsigned char* const clsr = a.cls + a.mlead;    // row-based
+
+    int c0[NC], c1[NC], c2[NC];
+    double f0[NC], f1[NC], f2[NC], ap0[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], vd[NC];
+    double hxv[LPW], hyv[2];
+    int hxc[LPW], hyc[2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { f0[c] = ap0[c] = w0[c] = w1[c] = 0.0; }
+
+    auto load_plane = [&](const int plane, const bool on, int (&cc)[NC], double (&fr)[NC]) {
+        const int64_t o = (int64_t)plane * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r = rowof(c) + o;
+            const bool ok = on && r >= a.slo && r < a.nloc;
+            cc[c] = *(ok ? clsr + r : zc);
+            fr[c] = j2_ld<false>(a.f + r, ok && r >= 0, a.zero);
+        }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o;
+            const bool okx = on && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
+            const bool okh = okx && hl && hrow >= a.slo && hrow < a.nloc;
+            hxv[l] = j2_ld<false>(a.x + hrow, okx, a.zero);
+            hxc[l] = *(okh ? clsr + hrow : zc);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o;
+            const bool okx = on && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
+            const bool okh = okx && wlo && hrow >= a.slo && hrow < a.nloc;
+            hyv[r] = j2_ld<false>(a.x + hrow, okx, a.zero);
+            hyc[r] = *(okh ? clsr + hrow : zc);
+        }
+    };
+    auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
+        const int64_t o = (int64_t)plane * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r = rowof(c) + o;
+            v[c] = j2_ld<false>(a.x + r, on && r >= a.xlo && r < a.xhi, a.zero);
+        }
+    };
+    auto park = [&](const int slot, const double (&v)[NC], const int (&cc)[NC]) {
+        unsigned char* const cs = sC + slot * ((EY + 2) * PV);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iv = lvof(c);
+            sV0[iv] = v[c];
+            cs[iv] = (unsigned char)cc[c];
+        }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            const int rowv = (ey0 + l + 1) * PV;
+            if (hl) { sV0[rowv] = hxv[l]; cs[rowv] = (unsigned char)hxc[l]; }
+            if (hr) sV0[rowv + EX + 1] = hxv[l];
+        }
+        if (wlo) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; cs[lane + 64 * r + 1] = (unsigned char)hyc[r]; }
+        } else if (whi) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
+        }
+    };
+
+    load_plane(z0 - 1, true, c1, f1);
+    load_x(z0 - 2, true, va);
+    load_x(z0 - 1, true, vb);
+    load_x(z0, true, vc);
+    {
+        const int64_t o = (int64_t)(z0 - 2) * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t r = rowof(c) + o;
+            c0[c] = *((r >= a.slo && r < a.nloc) ? clsr + r : zc);
+        }
+    }
+    park((z0 - 1) & 1, vb, c1);
+    __syncthreads();
+
+    for (int k = z0 - 2; k < z1; ++k) {
+        load_plane(k + 2, k + 2 <= z1, c2, f2);
+        load_x(k + 3, k + 3 <= z1 + 1, vd);
+
+        const unsigned char* const cp = sC + ((k + 1) & 1) * ((EY + 2) * PV);     // classes of plane k+1
+        {
+            const int64_t o1 = (int64_t)(k + 1) * a.P;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int iv = lvof(c), iw = lwof(c);
+                const double s0 = sT[4 * c0[c] + 3];
+                const double* const t1 = sT + 4 * c1[c];
+                double acc = 0.0;
+                acc = fma(s0, va[c], acc);                                          // -P
+                acc = fma(sT[4 * cp[iv - PV] + 2], sV0[iv - PV], acc);              // -nx
+                acc = fma(sT[4 * cp[iv - 1] + 1], sV0[iv - 1], acc);                // -1
+                acc = fma(t1[0], vb[c], acc);
+                acc = fma(t1[1], sV0[iv + 1], acc);                                 // +1
+                acc = fma(t1[2], sV0[iv + PV], acc);                                // +nx
+                acc = fma(t1[3], vc[c], acc);                                       // +P
+                const double o = vb[c] + sCF[c1[c]] * (f1[c] - acc);
+                const int64_t r1 = rowof(c) + o1;
+                w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
+                sV1[iw] = w1[c];
+                if (inT >> c & 1u) {
+                    const int64_t r0 = r1 - a.P;
+                    if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi)
+                        a.out[r0] = w0[c] + sCF[c0[c]] * (f0[c] - fma(s0, w1[c], ap0[c]));
+                    if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (k >= z0 - 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double acc = 0.0;
+                if (inT >> c & 1u) {
+                    const int iv = lvof(c), iw = lwof(c);
+                    const double* const t1 = sT + 4 * c1[c];
+                    acc = fma(sT[4 * c0[c] + 3], w0[c], acc);
+                    acc = fma(sT[4 * cp[iv - PV] + 2], sV1[iw - EX], acc);
+                    acc = fma(sT[4 * cp[iv - 1] + 1], sV1[iw - 1], acc);
+                    acc = fma(t1[0], w1[c], acc);
+                    acc = fma(t1[1], sV1[iw + 1], acc);
+                    acc = fma(t1[2], sV1[iw + EX], acc);
+                }
+                ap0[c] = acc;
+            }
+        }
+        park(k & 1, vc, c2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            c0[c] = c1[c]; c1[c] = c2[c];
+            f0[c] = f1[c]; f1[c] = f2[c]; w0[c] = w1[c];
+            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NW, int LPW>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c(J2Args a) {
+    j2c_body<NW, LPW>(a);
+}
+
+// (its own symbol for the finest level, like sdia_jacobi2_finest)
+template <int NW, int LPW>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c_finest(J2Args a) {
+    j2c_body<NW, LPW>(a);
 }
 
 template <int R, int NW, int LPW, bool NT>

@@ -270,6 +270,9 @@ class DeviceHierarchy:
         out["replicated"] = bool(rep.value)
         out["offset_codes"] = max(0, int(codes.value))
         out["symmetric_diagonals"] = max(0, -int(codes.value))
+        ncls = C.c_int()
+        check(self._lib.mg_level_row_classes(self._h, self._idx(level), C.byref(ncls)))
+        out["row_classes"] = int(ncls.value)
         return out
 
     def memory_bytes(self) -> int:

@@ -776,11 +776,13 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3),
-                dict(fuse_segments=5, fuse_nontemporal=1), dict(rows_per_lane=1), dict(rows_per_lane=4, fuse_segments=2)]
+    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0),
+                dict(fuse_segments=5, fuse_nontemporal=1, fuse_classes=0), dict(rows_per_lane=1),
+                dict(rows_per_lane=4, fuse_segments=2), dict(rows_per_lane=1, row_classes=0)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
+        classes = make.get("row_classes", 1)
         with DeviceHierarchy.synthetic(3, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
             dev.set_tuning("fuse_min_rows", 0)
             for k, v in tune.items():
@@ -788,6 +790,8 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
             for level in range(lo + 1, hi + 1):
                 info = dev.level_info(level)
                 assert info["symmetric_diagonals"] == 4
+                # the generated Poisson rows: interior stencil, its variants next to the boundary, identity rows
+                assert (2 <= info["row_classes"] <= 64) if classes else info["row_classes"] == 0
                 n = info["n_global"]
                 if (level, "v") not in want:
                     want[level, "v"] = rng.standard_normal(n)
@@ -809,3 +813,48 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
                 want["res"] = res
             else:
                 assert np.all(np.abs(res - want["res"]) <= 1e-13 * want["res"]), kw
+
+
+def test_row_classes_fall_back_when_there_are_too_many_distinct_rows():
+    """Symmetric 7-point matrices with many distinct rows (the Poisson matrix scaled symmetrically by random powers of
+    two, which keeps it symmetric bit for bit) get no class dictionary: the two-sweep pass reads the rows themselves.
+    With only a few rows rescaled the dictionary grows by a few classes.  Same results as single sweeps either way."""
+    import scipy.sparse as sps
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(11)
+    bag = poisson.make_hierarchy(3, 1, 3, c=5, mu1=2, mu2=2, seed=None)         # 41^3 unknowns on the finest level
+    A = bag.A_sp_dict[3][0].tocsr()
+    n = A.shape[0]
+    v_in = rng.standard_normal(n)
+    base_classes = None
+    for case in ("plain", "few", "many"):
+        e = np.zeros(n)
+        if case == "few":
+            e[rng.choice(n, 5, replace=False)] = 1.0
+        elif case == "many":
+            e = rng.integers(0, 8, n).astype(np.float64)
+        d = sps.diags(2.0 ** e)
+        B = (d @ A @ d).tocsr()
+        outs = []
+        for fuse in (0, 1):
+            with DeviceHierarchy(3, 1, 3, c=5) as dev:
+                dev.set_tuning("fuse_min_rows", 0)
+                dev.set_tuning("fuse_sweeps", fuse)
+                for l in (1, 2):
+                    dev.set_level(l, bag.A_sp_dict[l][0], bag.levels[l].grid_index)
+                dev.set_level(3, B, bag.levels[3].grid_index)
+                dev.set_params(4, 4, 2.0 / 3.0)
+                info = dev.level_info(3)
+                assert info["symmetric_diagonals"] == 4, info
+                if case == "plain":
+                    base_classes = info["row_classes"]
+                    assert 2 <= base_classes <= 64
+                elif case == "few":
+                    assert base_classes < info["row_classes"] <= base_classes + 80
+                else:
+                    assert info["row_classes"] == 0
+                dev.set_vector(3, "v", v_in)
+                dev.set_vector(3, "f", bag.b_dict[3])
+                dev.smooth(3, 5)
+                outs.append(dev.get_vector(3, "v"))
+        assert np.array_equal(outs[0], outs[1]), case
