@@ -218,6 +218,7 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
+    int fuse_shape = 2;             // launch shape of the class-coded pass (launch_jacobi2); 2 measured best
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -692,10 +693,16 @@ constexpr int kJ2Lines = 16;        // grid lines per tile (8 waves x 2)
 //     boundary work that the exchanges wait for is small, the interior cut by the same cost model.
 struct J2Plan { int ntx, nty, nseg, zb, seglen; };
 
+// grid lines per tile: 16 for the plain pass; the class-coded pass has shapes with 16 and 32 ("fuse_shape")
+int jacobi2_lines(const mg_context* c, const Level& L) {
+    return kJ2Lines;
+}
+
 J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boundary_rows) {
     J2Plan p{};
+    const int lines = jacobi2_lines(c, L);
     p.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
-    p.nty = (L.g.ny + kJ2Lines - 3) / (kJ2Lines - 2);
+    p.nty = (L.g.ny + lines - 3) / (lines - 2);
     const int64_t ntile = (int64_t)p.ntx * p.nty;
     const int nk = L.g.nk;
     auto pieces = [&](int planes, int most) {
@@ -732,9 +739,8 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     return p;
 }
 
-template <int NW, int LPW>
+template <int NW, int LPW, bool DEEP>
 int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
-    static_assert(NW * LPW == kJ2Lines, "tile height");
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
     if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
     J2Args b = a;
@@ -742,7 +748,7 @@ int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
     constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
     static bool attr_set = false;
-    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
+    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW, DEEP>, sdia_jacobi2c_finest<NW, LPW, DEEP>};
     if (!attr_set) {
         for (auto* k : kern)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -797,7 +803,11 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     if (L.cls && c->fuse_classes) {
         a.cls = L.cls; a.ctab = L.ctab;
-        return launch_jacobi2c_t<8, 2>(c, a, n, finest);
+        switch (c->fuse_shape) {
+            case 1: return launch_jacobi2c_t<8, 2, true>(c, a, n, finest);      // 16 lines, 512 threads, loads two steps ahead
+            case 2: return launch_jacobi2c_t<16, 1, false>(c, a, n, finest);    // 16 lines, 1024 threads
+            default: return launch_jacobi2c_t<8, 2, false>(c, a, n, finest);    // 16 lines, 512 threads
+        }
     }
     if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
     if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n, finest);
@@ -1713,6 +1723,9 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_sweeps = value != 0;
     } else if (k == "fuse_min_rows") {
         c->fuse_min_rows = value;
+    } else if (k == "fuse_shape") {
+        if (value < 0 || value > 2) return fail("fuse_shape must be 0..2");
+        c->fuse_shape = (int)value;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;
     } else if (k == "fuse_nontemporal") {
