@@ -326,7 +326,9 @@ def main():
         try:
             t = json.load(open(tpath))
             key = f"{args.config}_gpus{args.gpus}"
-            traffic = t.get(key, {}).get("jacobi2_hbm_bytes_per_launch" if pair_ms else "jacobi_hbm_bytes_per_launch")
+            classes = bool(pair_ms) and info.get("row_classes", 0) > 0 and not any(kv.startswith("fuse_classes=0") for kv in args.tune)
+            traffic = t.get(key, {}).get(("jacobi2c_hbm_bytes_per_launch" if classes else "jacobi2_hbm_bytes_per_launch")
+                                         if pair_ms else "jacobi_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -355,11 +357,14 @@ def main():
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sdia_jacobi2<...> (two fine-level weighted-Jacobi sweeps per launch)" if pair_ms else
+                         "kernel": (("sdia_jacobi2c<...> (two fine-level weighted-Jacobi sweeps per launch, class-coded rows)"
+                                     if info.get("row_classes", 0) > 0 else
+                                     "sdia_jacobi2<...> (two fine-level weighted-Jacobi sweeps per launch)")) if pair_ms else
                                    ("sdia_apply" if info["symmetric_diagonals"] else
                                     "ell_apply_coded" if info["offset_codes"] else "ell_apply")
                                    + "<..., MODE_JACOBI> (fine-level weighted-Jacobi sweep)",
                          "sweeps_per_launch": sweeps_per_launch, "single_sweep_kernel_ms": jac_ms,
+                         "row_classes": info.get("row_classes", 0),
                          "storage": ("symmetric diagonals" if info["symmetric_diagonals"] else
                                      "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": bytes_launch,
