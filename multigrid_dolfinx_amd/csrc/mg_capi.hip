@@ -145,6 +145,7 @@ struct Level {
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
     int ncls = 0;
+    int64_t cls_lead = 0, cls_rows = 0;     // cls[row + cls_lead], zero padding of cls_lead entries on both sides
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
     DVector sw;                             // once-relaxed boundary planes of a slab (paired sweeps, world > 1)
@@ -218,7 +219,7 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
-    int fuse_shape = 2;             // launch shape of the class-coded pass (launch_jacobi2); 2 measured best
+    int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -257,7 +258,8 @@ void dev_free(mg_context* c, T*& p, size_t count) {
 // offsets reach further keeps the coded format (repack_sdia checks against vec_reach).
 constexpr int64_t kVecSlack = 260;
 
-inline int64_t vec_reach(const Level& L) { return L.flat ? 0 : L.g.plane + L.g.nx + 4; }
+// (the class-coded two-sweep pass reads whole tiles without per-lane predicates: a plane + 2 lines + 2 beyond either end)
+inline int64_t vec_reach(const Level& L) { return L.flat ? 0 : L.g.plane + 2 * (int64_t)L.g.nx + 8; }
 inline int64_t vec_front(const Level& L) {
     // the first owned row starts a 128-byte line (hipMalloc returns 256-byte aligned memory)
     const int64_t slack = ((vec_reach(L) + 15) / 16) * 16;
@@ -384,7 +386,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.codes, (size_t)L.nslices * ((L.W + 7) / 8) * (WAVE * L.R));
     dev_free(c, L.offsets, 256);
     dev_free(c, L.dvals, (size_t)L.mslices * (L.wu > 0 ? L.wu : 1) * (WAVE * L.R));
-    dev_free(c, L.cls, (size_t)L.mslices * (WAVE * L.R));
+    dev_free(c, L.cls, (size_t)L.cls_rows);
     dev_free(c, L.ctab, 256 * 4);
     L.ncls = 0;
     L.coded = false;
@@ -695,7 +697,7 @@ struct J2Plan { int ntx, nty, nseg, zb, seglen; };
 
 // grid lines per tile: 16 for the plain pass; the class-coded pass has shapes with 16 and 32 ("fuse_shape")
 int jacobi2_lines(const mg_context* c, const Level& L) {
-    return kJ2Lines;
+    return (L.cls && c->fuse_classes && (c->fuse_shape == 1 || c->fuse_shape == 3)) ? 24 : kJ2Lines;
 }
 
 J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boundary_rows) {
@@ -739,7 +741,7 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     return p;
 }
 
-template <int NW, int LPW, bool DEEP>
+template <int NW, int LPW>
 int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
     if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
@@ -748,7 +750,7 @@ int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
     constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
     static bool attr_set = false;
-    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW, DEEP>, sdia_jacobi2c_finest<NW, LPW, DEEP>};
+    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
     if (!attr_set) {
         for (auto* k : kern)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -802,11 +804,12 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     // 8 waves x 2 grid lines each (16 waves x 1 line measured slower and does not fit 128 registers)
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     if (L.cls && c->fuse_classes) {
-        a.cls = L.cls; a.ctab = L.ctab;
+        a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead;
         switch (c->fuse_shape) {
-            case 1: return launch_jacobi2c_t<8, 2, true>(c, a, n, finest);      // 16 lines, 512 threads, loads two steps ahead
-            case 2: return launch_jacobi2c_t<16, 1, false>(c, a, n, finest);    // 16 lines, 1024 threads
-            default: return launch_jacobi2c_t<8, 2, false>(c, a, n, finest);    // 16 lines, 512 threads
+            case 1: return launch_jacobi2c_t<12, 2>(c, a, n, finest);      // 24 lines, 768 threads
+            case 2: return launch_jacobi2c_t<16, 1>(c, a, n, finest);      // 16 lines, 1024 threads
+            case 3: return launch_jacobi2c_t<8, 3>(c, a, n, finest);       // 24 lines, 512 threads
+            default: return launch_jacobi2c_t<8, 2>(c, a, n, finest);      // 16 lines, 512 threads
         }
     }
     if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
@@ -1369,14 +1372,18 @@ int build_row_classes(mg_context* c, Level& L) {
     struct { unsigned long long* p; } tags{reinterpret_cast<unsigned long long*>(scratch.p)};
     struct { double* p; } svals{reinterpret_cast<double*>(scratch.p + tag_bytes)};
     struct { int* p; } ints{reinterpret_cast<int*>(scratch.p + tag_bytes + val_bytes)};
+    // padded like the vectors (vec_reach) so that the pass can read whole tiles around the level unpredicated
+    const int64_t cls_lead = ((std::max(L.mlead, vec_reach(L)) + 255) / 256) * 256;
+    const int64_t cls_rows = cls_lead + L.nloc + cls_lead + 512;
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
-    MG_TRY(dev_alloc(c, &cls, (size_t)mrows));
+    MG_TRY(dev_alloc(c, &cls, (size_t)cls_rows));
     MG_TRY(dev_alloc(c, &ctab, 256 * 4));
     ClsArgs a{};
     a.dvals = L.dvals; a.mrows = mrows; a.tags = tags.p; a.svals = svals.p; a.count = ints.p; a.flag = ints.p + 1;
     a.slot_class = ints.p + 2; a.ctab = ctab; a.cls = cls;
-    const dim3 grid(blocks_for(mrows, 256)), blk(256);
+    a.crows = cls_rows; a.cshift = cls_lead - L.mlead;
+    const dim3 grid(blocks_for(mrows, 256)), egrid(blocks_for(cls_rows, 256)), blk(256);
     int h[2] = {0, 0};
     int rc = [&]() -> int {
         switch (L.R) {
@@ -1386,9 +1393,9 @@ int build_row_classes(mg_context* c, Level& L) {
         }
         hipLaunchKernelGGL(cls_assign, dim3(1), dim3(64), 0, c->stream, a);
         switch (L.R) {
-            case 1: hipLaunchKernelGGL(cls_encode<64>, grid, blk, 0, c->stream, a); break;
-            case 2: hipLaunchKernelGGL(cls_encode<128>, grid, blk, 0, c->stream, a); break;
-            default: hipLaunchKernelGGL(cls_encode<256>, grid, blk, 0, c->stream, a); break;
+            case 1: hipLaunchKernelGGL(cls_encode<64>, egrid, blk, 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(cls_encode<128>, egrid, blk, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(cls_encode<256>, egrid, blk, 0, c->stream, a); break;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h, ints.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1396,11 +1403,11 @@ int build_row_classes(mg_context* c, Level& L) {
         return 0;
     }();
     if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass
-        dev_free(c, cls, (size_t)mrows);
+        dev_free(c, cls, (size_t)cls_rows);
         dev_free(c, ctab, 256 * 4);
         return rc;
     }
-    L.cls = cls; L.ctab = ctab; L.ncls = h[0] + 1;
+    L.cls = cls; L.ctab = ctab; L.ncls = h[0] + 1; L.cls_lead = cls_lead; L.cls_rows = cls_rows;
     return 0;
 }
 
@@ -1724,7 +1731,7 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_min_rows") {
         c->fuse_min_rows = value;
     } else if (k == "fuse_shape") {
-        if (value < 0 || value > 2) return fail("fuse_shape must be 0..2");
+        if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;

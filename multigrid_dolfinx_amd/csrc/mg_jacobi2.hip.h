@@ -40,6 +40,7 @@ struct J2Args {
     // row classes (sdia_jacobi2c): cls[row + mlead] indexes ctab[class][4] = (diagonal, +1, +nx, +P entries)
     const unsigned char* cls;
     const double* ctab;
+    int64_t clead;          // padding in front of cls[]: class of row r is cls[r + clead]
     int nx, ny, nz;
     // plane segments: 0 = [0, zb), nseg-1 = [nz-zb, nz), the others cut [zb, nz-zb) into pieces of seglen planes;
     // this launch covers the segments seg0, seg0 + seg_stride, ... (nitems / (ntx*nty) of them)
@@ -297,7 +298,8 @@ struct ClsArgs {
     int* count;                     // distinct non-zero rows seen
     int* slot_class;                // CLS_SLOTS
     double* ctab;                   // 256 x 4
-    unsigned char* cls;             // mrows
+    unsigned char* cls;             // crows: cls[i] is the class of stored row i - cshift (class 0 where there is none)
+    int64_t crows, cshift;
     int* flag;                      // set when a row does not match its dictionary entry
 };
 
@@ -366,11 +368,13 @@ __global__ void cls_assign(ClsArgs a) {
 
 template <int S>
 __global__ void cls_encode(ClsArgs a) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= a.mrows) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.crows) return;
+    const int64_t m = i - a.cshift;
+    if (m < 0 || m >= a.mrows) { a.cls[i] = 0; return; }
     unsigned long long b[4];
     cls_row<S>(a, m, b);
-    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) { a.cls[m] = 0; return; }
+    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) { a.cls[i] = 0; return; }
     const unsigned long long h = cls_hash(b);
     unsigned s = (unsigned)h & (CLS_SLOTS - 1);
     for (int probe = 0; probe < CLS_SLOTS; ++probe) {
@@ -380,14 +384,14 @@ __global__ void cls_encode(ClsArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) same = same && (unsigned long long)__double_as_longlong(a.svals[4 * s + c]) == b[c];
             if (!same || a.slot_class[s] == 0) atomicExch(a.flag, 1);       // hash collision / overflow: no classes
-            a.cls[m] = (unsigned char)a.slot_class[s];
+            a.cls[i] = (unsigned char)a.slot_class[s];
             return;
         }
         if (t == 0ull) break;
         s = (s + 1) & (CLS_SLOTS - 1);
     }
     atomicExch(a.flag, 1);
-    a.cls[m] = 0;
+    a.cls[i] = 0;
 }
 
 // ---- the two-sweep pass on class-coded rows ----------------------------------------------------
@@ -447,50 +451,96 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
         const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
         if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
     }
-    const bool hl = lane == 0, hr = lane == 63;
+    const bool hl = lane == 0;
     const bool wlo = wave == 0, whi = wave == NW - 1;
-    const unsigned char* const zc = reinterpret_cast<const unsigned char*>(a.zero);
-    const unsigned char* const clsr = a.cls + a.mlead;    // row-based
+
+    // Addresses.  Every load of a plane is `uniform base of the plane + a 32-bit element offset fixed for the whole
+    // march`: no per-lane predicates, no 64-bit address arithmetic in the loop.  That needs every address to be
+    // readable whether or not its row exists: the vectors carry zero slack of a plane + 2 lines on both sides
+    // (vec_reach), the class array is padded alike with class 0 (the all-zero row), planes -1 and nz are read like
+    // any other and planes beyond them are skipped by a uniform test.  Grid lines from ny+2 on (tiles that stick
+    // out of the grid; their cells feed no result) are read at line ny+1 so that the slack suffices.
+    const unsigned bias = 2u * (unsigned)a.nx + 2u;
+    unsigned eo[LPW], eor;                                   // cell (line l, r = 0); the line of the y ring
+#pragma unroll
+    for (int l = 0; l < LPW; ++l)
+        eo[l] = (unsigned)((int64_t)min(ty0 + ey0 + l, a.ny + 1) * a.nx + tx0 + lane + (int64_t)bias);
+    eor = (unsigned)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + lane + (int64_t)bias);
+    const unsigned char* const clsb = a.cls + a.clead - bias;       // + plane*P: class of element offset 0
+    const double* const xb0 = a.x - bias;
+    const double* const fb0 = a.f - bias;
+    // the plane bases are made opaque scalars (readfirstlane) so that the compiler keeps them in SGPRs and emits
+    // `global_load v, v_offset, s[base:base+1] offset:imm` instead of carrying a 64-bit VGPR address per stream
+    auto sbase = [](const void* p) -> const char* {
+        const unsigned long long u = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto ldd = [](const char* b, unsigned e, int d) -> double { return *reinterpret_cast<const double*>(b + (e << 3) + d * 8); };
+    auto ldc = [](const char* b, unsigned e, int d) -> int { return *reinterpret_cast<const unsigned char*>(b + e + d); };
 
     int c0[NC], c1[NC], c2[NC];
     double f0[NC], f1[NC], f2[NC], ap0[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], vd[NC];
-    double hxv[LPW], hyv[2];
+    double hxl[LPW], hyv[2];
     int hxc[LPW], hyc[2];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { f0[c] = ap0[c] = w0[c] = w1[c] = 0.0; }
+#pragma unroll
+    for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
+    hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
 
     auto load_plane = [&](const int plane, const bool on, int (&cc)[NC], double (&fr)[NC]) {
-        const int64_t o = (int64_t)plane * a.P;
+        if (on && plane >= -1 && plane <= a.nz) {
+            const int64_t o = (int64_t)plane * a.P;
+            const char* const cb = sbase(clsb + o);
+            const char* const fb = sbase(fb0 + o);
+            const char* const xb = sbase(xb0 + o);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            const bool ok = on && r >= a.slo && r < a.nloc;
-            cc[c] = *(ok ? clsr + r : zc);
-            fr[c] = j2_ld<false>(a.f + r, ok && r >= 0, a.zero);
-        }
+            for (int c = 0; c < NC; ++c) {
+                cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
+                fr[c] = ldd(fb, eo[c >> 1], 64 * (c & 1));
+            }
+            if (hl || lane == 63) {                 // x ring: the cell left of ex = 0 / right of ex = EX-1
 #pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o;
-            const bool okx = on && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
-            const bool okh = okx && hl && hrow >= a.slo && hrow < a.nloc;
-            hxv[l] = j2_ld<false>(a.x + hrow, okx, a.zero);
-            hxc[l] = *(okh ? clsr + hrow : zc);
-        }
+                for (int l = 0; l < LPW; ++l) {
+                    hxl[l] = ldd(xb, hl ? eo[l] - 1u : eo[l] + 65u, 0);
+                    hxc[l] = ldc(cb, eo[l], -1);
+                }
+            }
+            if (wlo || whi) {                       // y ring: the line below ey = 0 / above ey = EY-1
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o;
-            const bool okx = on && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
-            const bool okh = okx && wlo && hrow >= a.slo && hrow < a.nloc;
-            hyv[r] = j2_ld<false>(a.x + hrow, okx, a.zero);
-            hyc[r] = *(okh ? clsr + hrow : zc);
+                for (int r = 0; r < 2; ++r) {
+                    hyv[r] = ldd(xb, eor, 64 * r);
+                    hyc[r] = ldc(cb, eor, 64 * r);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { cc[c] = 0; fr[c] = 0.0; }
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
+            hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
         }
     };
     auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
-        const int64_t o = (int64_t)plane * a.P;
+        if (on && plane >= -1 && plane <= a.nz) {
+            const char* const xb = sbase(xb0 + (int64_t)plane * a.P);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            v[c] = j2_ld<false>(a.x + r, on && r >= a.xlo && r < a.xhi, a.zero);
+            for (int c = 0; c < NC; ++c) v[c] = ldd(xb, eo[c >> 1], 64 * (c & 1));
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = 0.0;
+        }
+    };
+    auto load_c = [&](const int plane, int (&cc)[NC]) {
+        if (plane >= -1 && plane <= a.nz) {
+            const char* const cb = sbase(clsb + (int64_t)plane * a.P);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cc[c] = 0;
         }
     };
     auto park = [&](const int slot, const double (&v)[NC], const int (&cc)[NC]) {
@@ -504,8 +554,8 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
 #pragma unroll
         for (int l = 0; l < LPW; ++l) {
             const int rowv = (ey0 + l + 1) * PV;
-            if (hl) { sV0[rowv] = hxv[l]; cs[rowv] = (unsigned char)hxc[l]; }
-            if (hr) sV0[rowv + EX + 1] = hxv[l];
+            if (hl) { sV0[rowv] = hxl[l]; cs[rowv] = (unsigned char)hxc[l]; }
+            if (lane == 63) sV0[rowv + EX + 1] = hxl[l];
         }
         if (wlo) {
 #pragma unroll
@@ -520,14 +570,7 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     load_x(z0 - 2, true, va);
     load_x(z0 - 1, true, vb);
     load_x(z0, true, vc);
-    {
-        const int64_t o = (int64_t)(z0 - 2) * a.P;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            c0[c] = *((r >= a.slo && r < a.nloc) ? clsr + r : zc);
-        }
-    }
+    load_c(z0 - 2, c0);
     park((z0 - 1) & 1, vb, c1);
     __syncthreads();
 
@@ -593,226 +636,14 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
 }
 
 template <int NW, int LPW>
-__device__ __forceinline__ void j2c_body_deep(const J2Args& a) {
-    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
-    extern __shared__ double j2_smem[];
-    double* const sT = j2_smem;                           // 256 x 4    entries of the row classes
-    double* const sCF = sT + 256 * 4;                     // 256        omega / diagonal
-    double* const sV0 = sCF + 256;                        // (EY+2) x PV   x of one plane, origin (-1,-1)
-    double* const sV1 = sV0 + (EY + 2) * PV;              // EY x EX       once-relaxed iterate of one plane
-    unsigned char* const sC = reinterpret_cast<unsigned char*>(sV1 + EY * EX);   // 2 x (EY+2) x PV classes, like sV0
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    unsigned id;
-    {
-        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-        id = ((j >> 5) * 8u + xcd) * 32u + (j & 31u);
-    }
-    if (id >= a.nitems) return;
-    const unsigned ntile = (unsigned)(a.ntx * a.nty);
-    const int seg = a.seg0 + (int)(id / ntile) * a.seg_stride;
-    const unsigned t = id % ntile;
-    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
-    int z0, z1;
-    if (seg == 0) { z0 = 0; z1 = min(a.zb, a.nz); }
-    else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
-    else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
-    if (z1 <= z0) return;
-    const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;
-
-    for (int i = threadIdx.x; i < 256 * 4; i += NW * WAVE) sT[i] = a.ctab[i];
-    for (int i = threadIdx.x; i < 256; i += NW * WAVE) {
-        const double d = a.ctab[4 * i];
-        sCF[i] = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
-    }
-
-    const int ey0 = wave * LPW;
-    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
-    const int lv0 = (ey0 + 1) * PV + lane + 1;
-    const int lw0 = ey0 * EX + lane;
-    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
-    auto lvof = [&](int c) -> int { return lv0 + (c >> 1) * PV + 64 * (c & 1); };
-    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
-    unsigned inT = 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
-        if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
-    }
-    const bool hl = lane == 0, hr = lane == 63;
-    const bool wlo = wave == 0, whi = wave == NW - 1;
-    const unsigned char* const zc = reinterpret_cast<const unsigned char*>(a.zero);
-    const unsigned char* const clsr = a.cls + a.mlead;    // row-based
-
-    // registers.  Loads land in two slots that swap roles every step (P: issued a step ago -- class, f and ring of
-    // plane k+2, x of plane k+3; N: issued now -- plane k+3 / k+4), and only values that arrived a step earlier are
-    // ever copied, so every load has two steps to complete.
-    int c0[NC], c1[NC], cP[NC], cN[NC];
-    double f0[NC], f1[NC], fP[NC], fN[NC], ap0[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], xP[NC], xN[NC];
-    double hxvP[LPW], hyvP[2], hxvN[LPW], hyvN[2];
-    int hxcP[LPW], hycP[2], hxcN[LPW], hycN[2];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { f0[c] = ap0[c] = w0[c] = w1[c] = 0.0; }
-
-    auto load_plane = [&](const int plane, const bool on, int (&cc)[NC], double (&fr)[NC], double (&hxv)[LPW],
-                          double (&hyv)[2], int (&hxc)[LPW], int (&hyc)[2]) {
-        const int64_t o = (int64_t)plane * a.P;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            const bool ok = on && r >= a.slo && r < a.nloc;
-            cc[c] = *(ok ? clsr + r : zc);
-            fr[c] = j2_ld<false>(a.f + r, ok && r >= 0, a.zero);
-        }
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            const int64_t hrow = (hl ? rowof(2 * l) - 1 : rowof(2 * l + 1) + 1) + o;
-            const bool okx = on && (hl || hr) && hrow >= a.xlo && hrow < a.xhi;
-            const bool okh = okx && hl && hrow >= a.slo && hrow < a.nloc;
-            hxv[l] = j2_ld<false>(a.x + hrow, okx, a.zero);
-            hxc[l] = *(okh ? clsr + hrow : zc);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t hrow = (wlo ? rowof(r) - a.nx : rowof(2 * (LPW - 1) + r) + a.nx) + o;
-            const bool okx = on && (wlo || whi) && hrow >= a.xlo && hrow < a.xhi;
-            const bool okh = okx && wlo && hrow >= a.slo && hrow < a.nloc;
-            hyv[r] = j2_ld<false>(a.x + hrow, okx, a.zero);
-            hyc[r] = *(okh ? clsr + hrow : zc);
-        }
-    };
-    auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
-        const int64_t o = (int64_t)plane * a.P;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            v[c] = j2_ld<false>(a.x + r, on && r >= a.xlo && r < a.xhi, a.zero);
-        }
-    };
-    auto park = [&](const int slot, const double (&v)[NC], const int (&cc)[NC], const double (&hxv)[LPW],
-                    const double (&hyv)[2], const int (&hxc)[LPW], const int (&hyc)[2]) {
-        unsigned char* const cs = sC + slot * ((EY + 2) * PV);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int iv = lvof(c);
-            sV0[iv] = v[c];
-            cs[iv] = (unsigned char)cc[c];
-        }
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            const int rowv = (ey0 + l + 1) * PV;
-            if (hl) { sV0[rowv] = hxv[l]; cs[rowv] = (unsigned char)hxc[l]; }
-            if (hr) sV0[rowv + EX + 1] = hxv[l];
-        }
-        if (wlo) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; cs[lane + 64 * r + 1] = (unsigned char)hyc[r]; }
-        } else if (whi) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
-        }
-    };
-
-    // ---- warm-up: the image of plane z0-1, the registers of the first step (k = z0-2) and its P slot ----
-    load_plane(z0 - 1, true, c1, f1, hxvN, hyvN, hxcN, hycN);
-    load_x(z0 - 2, true, va);
-    load_x(z0 - 1, true, vb);
-    load_x(z0, true, vc);
-    {
-        const int64_t o = (int64_t)(z0 - 2) * a.P;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t r = rowof(c) + o;
-            c0[c] = *((r >= a.slo && r < a.nloc) ? clsr + r : zc);
-        }
-    }
-    load_plane(z0, true, cP, fP, hxvP, hyvP, hxcP, hycP);
-    load_x(z0 + 1, true, xP);
-    park((z0 - 1) & 1, vb, c1, hxvN, hyvN, hxcN, hycN);
-    __syncthreads();
-
-    auto step = [&](const int k, int (&cP)[NC], double (&fP)[NC], double (&xP)[NC], double (&hxvP)[LPW], double (&hyvP)[2],
-                    int (&hxcP)[LPW], int (&hycP)[2], int (&cN)[NC], double (&fN)[NC], double (&xN)[NC],
-                    double (&hxvN)[LPW], double (&hyvN)[2], int (&hxcN)[LPW], int (&hycN)[2]) {
-        load_plane(k + 3, k + 3 <= z1, cN, fN, hxvN, hyvN, hxcN, hycN);
-        load_x(k + 4, k + 4 <= z1 + 1, xN);
-
-        const unsigned char* const cp = sC + ((k + 1) & 1) * ((EY + 2) * PV);     // classes of plane k+1
-        {
-            const int64_t o1 = (int64_t)(k + 1) * a.P;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int iv = lvof(c), iw = lwof(c);
-                const double s0 = sT[4 * c0[c] + 3];
-                const double* const t1 = sT + 4 * c1[c];
-                double acc = 0.0;
-                acc = fma(s0, va[c], acc);                                          // -P
-                acc = fma(sT[4 * cp[iv - PV] + 2], sV0[iv - PV], acc);              // -nx
-                acc = fma(sT[4 * cp[iv - 1] + 1], sV0[iv - 1], acc);                // -1
-                acc = fma(t1[0], vb[c], acc);
-                acc = fma(t1[1], sV0[iv + 1], acc);                                 // +1
-                acc = fma(t1[2], sV0[iv + PV], acc);                                // +nx
-                acc = fma(t1[3], vc[c], acc);                                       // +P
-                const double o = vb[c] + sCF[c1[c]] * (f1[c] - acc);
-                const int64_t r1 = rowof(c) + o1;
-                w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
-                sV1[iw] = w1[c];
-                if (inT >> c & 1u) {
-                    const int64_t r0 = r1 - a.P;
-                    if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi)
-                        a.out[r0] = w0[c] + sCF[c0[c]] * (f0[c] - fma(s0, w1[c], ap0[c]));
-                    if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (k >= z0 - 1) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                double acc = 0.0;
-                if (inT >> c & 1u) {
-                    const int iv = lvof(c), iw = lwof(c);
-                    const double* const t1 = sT + 4 * c1[c];
-                    acc = fma(sT[4 * c0[c] + 3], w0[c], acc);
-                    acc = fma(sT[4 * cp[iv - PV] + 2], sV1[iw - EX], acc);
-                    acc = fma(sT[4 * cp[iv - 1] + 1], sV1[iw - 1], acc);
-                    acc = fma(t1[0], w1[c], acc);
-                    acc = fma(t1[1], sV1[iw + 1], acc);
-                    acc = fma(t1[2], sV1[iw + EX], acc);
-                }
-                ap0[c] = acc;
-            }
-        }
-        // park plane k+2: x arrived two steps ago (vc), class and ring were issued a step ago (slot P)
-        park(k & 1, vc, cP, hxvP, hyvP, hxcP, hycP);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            c0[c] = c1[c]; c1[c] = cP[c];
-            f0[c] = f1[c]; f1[c] = fP[c]; w0[c] = w1[c];
-            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = xP[c];
-        }
-        __syncthreads();
-    };
-
-    int k = z0 - 2;
-    for (; k + 1 < z1; k += 2) {
-        step(k, cP, fP, xP, hxvP, hyvP, hxcP, hycP, cN, fN, xN, hxvN, hyvN, hxcN, hycN);
-        step(k + 1, cN, fN, xN, hxvN, hyvN, hxcN, hycN, cP, fP, xP, hxvP, hyvP, hxcP, hycP);
-    }
-    if (k < z1) step(k, cP, fP, xP, hxvP, hyvP, hxcP, hycP, cN, fN, xN, hxvN, hyvN, hxcN, hycN);
-}
-
-template <int NW, int LPW, bool DEEP>
 __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c(J2Args a) {
-    if constexpr (DEEP) j2c_body_deep<NW, LPW>(a);
-    else j2c_body<NW, LPW>(a);
+    j2c_body<NW, LPW>(a);
 }
 
 // (its own symbol for the finest level, like sdia_jacobi2_finest)
-template <int NW, int LPW, bool DEEP>
+template <int NW, int LPW>
 __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c_finest(J2Args a) {
-    if constexpr (DEEP) j2c_body_deep<NW, LPW>(a);
-    else j2c_body<NW, LPW>(a);
+    j2c_body<NW, LPW>(a);
 }
 
 template <int R, int NW, int LPW, bool NT>
