@@ -160,8 +160,7 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "fuse_classes"       that pass reads one class byte per row instead of the 32-byte row where the level has
  *                          row classes (1); bit-identical either way
  *     "fuse_shape"         launch shape of the class-coded pass: 0 = 8 waves x 2 grid lines, 1 = 12 waves x 2 lines,
- *                          2 = 16 waves x 1 line, 3 = 8 waves x 3 lines, with two barriers per plane; 4, 5, 6 = the
- *                          shapes 1, 2, 3 with multi-buffered plane images and one barrier per plane (4)
+ *                          2 = 16 waves x 1 line, 3 = 8 waves x 3 lines (1)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
  *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)

@@ -219,7 +219,7 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
-    int fuse_shape = 4;             // launch shape of the class-coded pass (launch_jacobi2); 4 measured best
+    int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -699,7 +699,7 @@ struct J2Plan { int ntx, nty, nseg, zb, seglen; };
 int jacobi2_lines(const mg_context* c, const Level& L) {
     const int sh = c->fuse_shape;
     if (!(L.cls && c->fuse_classes)) return kJ2Lines;
-    return (sh == 1 || sh == 3 || sh == 4 || sh == 6) ? 24 : kJ2Lines;
+    return (sh == 1 || sh == 3) ? 24 : kJ2Lines;
 }
 
 J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boundary_rows) {
@@ -743,16 +743,16 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     return p;
 }
 
-template <int NW, int LPW, bool ONEBAR>
+template <int NW, int LPW>
 int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
     if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
     J2Args b = a;
     b.nitems = (unsigned)items;
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
-    constexpr size_t lds = j2c_lds_bytes<NW, LPW, ONEBAR>();
+    constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
     static bool attr_set = false;
-    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW, ONEBAR>, sdia_jacobi2c_finest<NW, LPW, ONEBAR>};
+    void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
     if (!attr_set) {
         for (auto* k : kern)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -808,13 +808,10 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     if (L.cls && c->fuse_classes) {
         a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead;
         switch (c->fuse_shape) {
-            case 1: return launch_jacobi2c_t<12, 2, false>(c, a, n, finest);     // 24 lines, 768 threads
-            case 2: return launch_jacobi2c_t<16, 1, false>(c, a, n, finest);     // 16 lines, 1024 threads
-            case 3: return launch_jacobi2c_t<8, 3, false>(c, a, n, finest);      // 24 lines, 512 threads
-            case 4: return launch_jacobi2c_t<12, 2, true>(c, a, n, finest);      // 24 lines, 768 threads, one barrier per plane
-            case 5: return launch_jacobi2c_t<16, 1, true>(c, a, n, finest);      // 16 lines, 1024 threads, one barrier per plane
-            case 6: return launch_jacobi2c_t<8, 3, true>(c, a, n, finest);       // 24 lines, 512 threads, one barrier per plane
-            default: return launch_jacobi2c_t<8, 2, false>(c, a, n, finest);     // 16 lines, 512 threads
+            case 0: return launch_jacobi2c_t<8, 2>(c, a, n, finest);       // 16 lines, 512 threads
+            case 2: return launch_jacobi2c_t<16, 1>(c, a, n, finest);      // 16 lines, 1024 threads
+            case 3: return launch_jacobi2c_t<8, 3>(c, a, n, finest);       // 24 lines, 512 threads
+            default: return launch_jacobi2c_t<12, 2>(c, a, n, finest);     // 24 lines, 768 threads (measured best)
         }
     }
     if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
@@ -1736,7 +1733,7 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_min_rows") {
         c->fuse_min_rows = value;
     } else if (k == "fuse_shape") {
-        if (value < 0 || value > 6) return fail("fuse_shape must be 0..6");
+        if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;

@@ -398,247 +398,18 @@ __global__ void cls_encode(ClsArgs a) {
 // Same march, same arithmetic as j2_body; per cell and step it loads one class byte, f and x (17 bytes instead of
 // 48) and keeps classes where j2_body keeps matrix entries: the row's own entries and omega/diag come from the LDS
 // table (sT, sCF: one IEEE division per class and workgroup instead of two per cell and step), the neighbours'
-// +1 / +nx entries through the plane image of the classes (sC).
-template <int NW, int LPW, bool ONEBAR> constexpr size_t j2c_lds_bytes() {
+// +1 / +nx entries through the plane image of the classes (sC).  With so few registers per cell the step is
+// arranged differently: the plane images are multi-buffered and the WHOLE second sweep of plane k is evaluated
+// in the step that relaxes plane k+1 once, from the image of v1[k] written a step earlier -- a step only reads
+// what earlier steps wrote, so there is one barrier per plane instead of two.
+template <int NW, int LPW> constexpr size_t j2c_lds_bytes() {
     constexpr int EY = NW * LPW, PV = J2_EX + 2;
     constexpr size_t v0 = (size_t)(EY + 2) * PV, v1 = (size_t)EY * J2_EX;
-    return ONEBAR ? sizeof(double) * (256 * 4 + 256 + 2 * v0 + 2 * v1) + 3 * v0
-                  : sizeof(double) * (256 * 4 + 256 + v0 + v1) + 2 * v0;
+    return sizeof(double) * (256 * 4 + 256 + 2 * v0 + 2 * v1) + 3 * v0;
 }
 
 template <int NW, int LPW>
 __device__ __forceinline__ void j2c_body(const J2Args& a) {
-    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
-    extern __shared__ double j2_smem[];
-    double* const sT = j2_smem;                           // 256 x 4    entries of the row classes
-    double* const sCF = sT + 256 * 4;                     // 256        omega / diagonal
-    double* const sV0 = sCF + 256;                        // (EY+2) x PV   x of one plane, origin (-1,-1)
-    double* const sV1 = sV0 + (EY + 2) * PV;              // EY x EX       once-relaxed iterate of one plane
-    unsigned char* const sC = reinterpret_cast<unsigned char*>(sV1 + EY * EX);   // 2 x (EY+2) x PV classes, like sV0
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    unsigned id;
-    {
-        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-        id = ((j >> 5) * 8u + xcd) * 32u + (j & 31u);
-    }
-    if (id >= a.nitems) return;
-    const unsigned ntile = (unsigned)(a.ntx * a.nty);
-    const int seg = a.seg0 + (int)(id / ntile) * a.seg_stride;
-    const unsigned t = id % ntile;
-    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
-    int z0, z1;
-    if (seg == 0) { z0 = 0; z1 = min(a.zb, a.nz); }
-    else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
-    else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
-    if (z1 <= z0) return;
-    const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;
-
-    for (int i = threadIdx.x; i < 256 * 4; i += NW * WAVE) sT[i] = a.ctab[i];
-    for (int i = threadIdx.x; i < 256; i += NW * WAVE) {
-        const double d = a.ctab[4 * i];
-        sCF[i] = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
-    }
-
-    const int ey0 = wave * LPW;
-    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
-    const int lv0 = (ey0 + 1) * PV + lane + 1;
-    const int lw0 = ey0 * EX + lane;
-    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
-    auto lvof = [&](int c) -> int { return lv0 + (c >> 1) * PV + 64 * (c & 1); };
-    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
-    unsigned inT = 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
-        if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
-    }
-    const bool hl = lane == 0;
-    const bool wlo = wave == 0, whi = wave == NW - 1;
-
-    // Addresses.  Every load of a plane is `uniform base of the plane + a 32-bit element offset fixed for the whole
-    // march`: no per-lane predicates, no 64-bit address arithmetic in the loop.  That needs every address to be
-    // readable whether or not its row exists: the vectors carry zero slack of a plane + 2 lines on both sides
-    // (vec_reach), the class array is padded alike with class 0 (the all-zero row), planes -1 and nz are read like
-    // any other and planes beyond them are skipped by a uniform test.  Grid lines from ny+2 on (tiles that stick
-    // out of the grid; their cells feed no result) are read at line ny+1 so that the slack suffices.
-    const unsigned bias = 2u * (unsigned)a.nx + 2u;
-    unsigned eo[LPW], eor;                                   // cell (line l, r = 0); the line of the y ring
-#pragma unroll
-    for (int l = 0; l < LPW; ++l)
-        eo[l] = (unsigned)((int64_t)min(ty0 + ey0 + l, a.ny + 1) * a.nx + tx0 + lane + (int64_t)bias);
-    eor = (unsigned)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + lane + (int64_t)bias);
-    const unsigned char* const clsb = a.cls + a.clead - bias;       // + plane*P: class of element offset 0
-    const double* const xb0 = a.x - bias;
-    const double* const fb0 = a.f - bias;
-    // the plane bases are made opaque scalars (readfirstlane) so that the compiler keeps them in SGPRs and emits
-    // `global_load v, v_offset, s[base:base+1] offset:imm` instead of carrying a 64-bit VGPR address per stream
-    auto sbase = [](const void* p) -> const char* {
-        const unsigned long long u = (unsigned long long)p;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-    };
-    auto ldd = [](const char* b, unsigned e, int d) -> double { return *reinterpret_cast<const double*>(b + (e << 3) + d * 8); };
-    auto ldc = [](const char* b, unsigned e, int d) -> int { return *reinterpret_cast<const unsigned char*>(b + e + d); };
-
-    int c0[NC], c1[NC], c2[NC];
-    double f0[NC], f1[NC], f2[NC], ap0[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], vd[NC];
-    double hxl[LPW], hyv[2];
-    int hxc[LPW], hyc[2];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { f0[c] = ap0[c] = w0[c] = w1[c] = 0.0; }
-#pragma unroll
-    for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
-    hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
-
-    auto load_plane = [&](const int plane, const bool on, int (&cc)[NC], double (&fr)[NC]) {
-        if (on && plane >= -1 && plane <= a.nz) {
-            const int64_t o = (int64_t)plane * a.P;
-            const char* const cb = sbase(clsb + o);
-            const char* const fb = sbase(fb0 + o);
-            const char* const xb = sbase(xb0 + o);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
-                fr[c] = ldd(fb, eo[c >> 1], 64 * (c & 1));
-            }
-            if (hl || lane == 63) {                 // x ring: the cell left of ex = 0 / right of ex = EX-1
-#pragma unroll
-                for (int l = 0; l < LPW; ++l) {
-                    hxl[l] = ldd(xb, hl ? eo[l] - 1u : eo[l] + 65u, 0);
-                    hxc[l] = ldc(cb, eo[l], -1);
-                }
-            }
-            if (wlo || whi) {                       // y ring: the line below ey = 0 / above ey = EY-1
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    hyv[r] = ldd(xb, eor, 64 * r);
-                    hyc[r] = ldc(cb, eor, 64 * r);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { cc[c] = 0; fr[c] = 0.0; }
-#pragma unroll
-            for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
-            hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
-        }
-    };
-    auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
-        if (on && plane >= -1 && plane <= a.nz) {
-            const char* const xb = sbase(xb0 + (int64_t)plane * a.P);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = ldd(xb, eo[c >> 1], 64 * (c & 1));
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = 0.0;
-        }
-    };
-    auto load_c = [&](const int plane, int (&cc)[NC]) {
-        if (plane >= -1 && plane <= a.nz) {
-            const char* const cb = sbase(clsb + (int64_t)plane * a.P);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cc[c] = 0;
-        }
-    };
-    auto park = [&](const int slot, const double (&v)[NC], const int (&cc)[NC]) {
-        unsigned char* const cs = sC + slot * ((EY + 2) * PV);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int iv = lvof(c);
-            sV0[iv] = v[c];
-            cs[iv] = (unsigned char)cc[c];
-        }
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            const int rowv = (ey0 + l + 1) * PV;
-            if (hl) { sV0[rowv] = hxl[l]; cs[rowv] = (unsigned char)hxc[l]; }
-            if (lane == 63) sV0[rowv + EX + 1] = hxl[l];
-        }
-        if (wlo) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) { sV0[lane + 64 * r + 1] = hyv[r]; cs[lane + 64 * r + 1] = (unsigned char)hyc[r]; }
-        } else if (whi) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) sV0[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
-        }
-    };
-
-    load_plane(z0 - 1, true, c1, f1);
-    load_x(z0 - 2, true, va);
-    load_x(z0 - 1, true, vb);
-    load_x(z0, true, vc);
-    load_c(z0 - 2, c0);
-    park((z0 - 1) & 1, vb, c1);
-    __syncthreads();
-
-    for (int k = z0 - 2; k < z1; ++k) {
-        load_plane(k + 2, k + 2 <= z1, c2, f2);
-        load_x(k + 3, k + 3 <= z1 + 1, vd);
-
-        const unsigned char* const cp = sC + ((k + 1) & 1) * ((EY + 2) * PV);     // classes of plane k+1
-        {
-            const int64_t o1 = (int64_t)(k + 1) * a.P;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int iv = lvof(c), iw = lwof(c);
-                const double s0 = sT[4 * c0[c] + 3];
-                const double* const t1 = sT + 4 * c1[c];
-                double acc = 0.0;
-                acc = fma(s0, va[c], acc);                                          // -P
-                acc = fma(sT[4 * cp[iv - PV] + 2], sV0[iv - PV], acc);              // -nx
-                acc = fma(sT[4 * cp[iv - 1] + 1], sV0[iv - 1], acc);                // -1
-                acc = fma(t1[0], vb[c], acc);
-                acc = fma(t1[1], sV0[iv + 1], acc);                                 // +1
-                acc = fma(t1[2], sV0[iv + PV], acc);                                // +nx
-                acc = fma(t1[3], vc[c], acc);                                       // +P
-                const double o = vb[c] + sCF[c1[c]] * (f1[c] - acc);
-                const int64_t r1 = rowof(c) + o1;
-                w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
-                sV1[iw] = w1[c];
-                if (inT >> c & 1u) {
-                    const int64_t r0 = r1 - a.P;
-                    if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi)
-                        a.out[r0] = w0[c] + sCF[c0[c]] * (f0[c] - fma(s0, w1[c], ap0[c]));
-                    if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (k >= z0 - 1) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                double acc = 0.0;
-                if (inT >> c & 1u) {
-                    const int iv = lvof(c), iw = lwof(c);
-                    const double* const t1 = sT + 4 * c1[c];
-                    acc = fma(sT[4 * c0[c] + 3], w0[c], acc);
-                    acc = fma(sT[4 * cp[iv - PV] + 2], sV1[iw - EX], acc);
-                    acc = fma(sT[4 * cp[iv - 1] + 1], sV1[iw - 1], acc);
-                    acc = fma(t1[0], w1[c], acc);
-                    acc = fma(t1[1], sV1[iw + 1], acc);
-                    acc = fma(t1[2], sV1[iw + EX], acc);
-                }
-                ap0[c] = acc;
-            }
-        }
-        park(k & 1, vc, c2);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            c0[c] = c1[c]; c1[c] = c2[c];
-            f0[c] = f1[c]; f1[c] = f2[c]; w0[c] = w1[c];
-            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
-        }
-        __syncthreads();
-    }
-}
-
-template <int NW, int LPW>
-__device__ __forceinline__ void j2c_body1(const J2Args& a) {
     constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
     extern __shared__ double j2_smem[];
     double* const sT = j2_smem;                           // 256 x 4    entries of the row classes
@@ -869,17 +640,15 @@ __device__ __forceinline__ void j2c_body1(const J2Args& a) {
     }
 }
 
-template <int NW, int LPW, bool ONEBAR>
+template <int NW, int LPW>
 __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c(J2Args a) {
-    if constexpr (ONEBAR) j2c_body1<NW, LPW>(a);
-    else j2c_body<NW, LPW>(a);
+    j2c_body<NW, LPW>(a);
 }
 
 // (its own symbol for the finest level, like sdia_jacobi2_finest)
-template <int NW, int LPW, bool ONEBAR>
+template <int NW, int LPW>
 __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2c_finest(J2Args a) {
-    if constexpr (ONEBAR) j2c_body1<NW, LPW>(a);
-    else j2c_body<NW, LPW>(a);
+    j2c_body<NW, LPW>(a);
 }
 
 template <int R, int NW, int LPW, bool NT>
