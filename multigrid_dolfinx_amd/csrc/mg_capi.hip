@@ -219,6 +219,7 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
+    std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
@@ -685,6 +686,15 @@ bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = fal
     return ignore_size || L.nloc >= c->fuse_min_rows;
 }
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per function (and device: one
+// device per handle); remembered in the handle.
+int allow_large_lds(mg_context* c, const void* kernel, size_t bytes) {
+    if (std::find(c->large_lds_kernels.begin(), c->large_lds_kernels.end(), kernel) != c->large_lds_kernels.end()) return 0;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    c->large_lds_kernels.push_back(kernel);
+    return 0;
+}
+
 constexpr int kJ2Lines = 16;        // grid lines per tile (8 waves x 2)
 
 // How a level's owned planes are cut into segments (one work item = one tile x one segment).  Segment 0 is
@@ -709,11 +719,12 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     p.nty = (L.g.ny + lines - 3) / (lines - 2);
     const int64_t ntile = (int64_t)p.ntx * p.nty;
     const int nk = L.g.nk;
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);      // one resident workgroup per CU
     auto pieces = [&](int planes, int most) {
         int best = 1;
         double best_cost = 1e300;
         for (int n = 1; n <= std::max(1, most); ++n) {
-            const double cost = (double)((ntile * n + 255) / 256) * ((planes + n - 1) / n + 2.5);
+            const double cost = (double)((ntile * n + cus - 1) / cus) * ((planes + n - 1) / n + 2.5);
             if (cost < best_cost) { best_cost = cost; best = n; }
         }
         return best;
@@ -751,13 +762,8 @@ int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     b.nitems = (unsigned)items;
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
     constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
-    static bool attr_set = false;
     void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
-    if (!attr_set) {
-        for (auto* k : kern)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
     hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -772,14 +778,9 @@ int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     b.nitems = (unsigned)items;
     const unsigned grid = (unsigned)((items + 255) / 256) * 256u;      // whole groups of 8 XCDs x 32 items
     constexpr size_t lds = j2_lds_bytes<NW, LPW>();
-    static bool attr_set = false;
     void (*const kern[4])(J2Args) = {sdia_jacobi2<R, NW, LPW, false>, sdia_jacobi2<R, NW, LPW, true>,
                                      sdia_jacobi2_finest<R, NW, LPW, false>, sdia_jacobi2_finest<R, NW, LPW, true>};
-    if (!attr_set) {
-        for (auto* k : kern)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[(finest ? 2 : 0) + (c->fuse_nontemporal ? 1 : 0)]), lds));
     hipLaunchKernelGGL(kern[(finest ? 2 : 0) + (c->fuse_nontemporal ? 1 : 0)], dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
     HIP_TRY(hipGetLastError());
     return 0;
