@@ -311,6 +311,15 @@ def main():
         pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
     except Exception:
         pair_ms = None
+    pair_plain_ms = None
+    if pair_ms and info.get("row_classes", 0) > 0:
+        # for the record: the same pass reading the 32-byte rows themselves (what a level with more than 255
+        # distinct rows -- variable coefficients -- would run)
+        try:
+            h.set_tuning("fuse_classes", 0)
+            pair_plain_ms = h.time_kernel("jacobi2", hi, max(2, args.kernel_reps // 2))
+        finally:
+            h.set_tuning("fuse_classes", 1 if not any(kv.startswith("fuse_classes=0") for kv in args.tune) else 0)
     n_loc, z_loc = info["n_local"], info["nnz_nonzero"]
     # ALGORITHMIC bytes (ELL form): values + int32 columns, read v f D^-1, write v -- what a
     # plain ELL sweep moves; the shipped formats move less (see roofline.traffic and DESIGN.md section 5)
@@ -364,6 +373,7 @@ def main():
                                     "ell_apply_coded" if info["offset_codes"] else "ell_apply")
                                    + "<..., MODE_JACOBI> (fine-level weighted-Jacobi sweep)",
                          "sweeps_per_launch": sweeps_per_launch, "single_sweep_kernel_ms": jac_ms,
+                         "kernel_ms_without_row_classes": pair_plain_ms,
                          "row_classes": info.get("row_classes", 0),
                          "storage": ("symmetric diagonals" if info["symmetric_diagonals"] else
                                      "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
