@@ -701,7 +701,7 @@ constexpr int kJ2Lines = 16;        // grid lines per tile (8 waves x 2)
 // [0, zb), the last one [nk-zb, nk), the others cut the planes between into pieces of `seglen`.
 //   whole levels: equal pieces, their number chosen by a cost model -- rounds of 256 resident workgroups times
 //     (planes per piece + ~2.5 plane-times of warm-up) -- which is what measured best on 1025^3 (8 pieces);
-//   slabs: zb short (the planes whose once-relaxed values travel to the neighbours, rounded up to 8), so that the
+//   slabs: zb short (the planes whose once-relaxed values travel to the neighbours, plus one), so that the
 //     boundary work that the exchanges wait for is small, the interior cut by the same cost model.
 struct J2Plan { int ntx, nty, nseg, zb, seglen; };
 
@@ -730,7 +730,8 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
         return best;
     };
     if (slab) {
-        const int zb = (int)std::max<int64_t>(8, ((boundary_rows + L.g.plane - 1) / L.g.plane + 7) / 8 * 8);
+        // one plane more than the rows the neighbours wait for (3 planes + 1 on a 1025^2 plane)
+        const int zb = (int)std::max<int64_t>(4, (boundary_rows + L.g.plane - 1) / L.g.plane + 1);
         if (nk >= 2 * zb + 8) {
             const int inner = nk - 2 * zb;
             int m = c->fuse_segments > 2 ? c->fuse_segments - 2 : pieces(inner, inner / 8);

@@ -858,3 +858,19 @@ def test_row_classes_fall_back_when_there_are_too_many_distinct_rows():
                 dev.smooth(3, 5)
                 outs.append(dev.get_vector(3, "v"))
         assert np.array_equal(outs[0], outs[1]), case
+
+
+def test_time_kernel_reports_where_the_two_sweep_pass_is_not_used():
+    """`mg_time_kernel("jacobi2")` is how bench.py finds out whether the smoother pairs sweeps on a level: an error on
+    levels where it does not (2-D, too small), a duration where it does."""
+    from multigrid_dolfinx_amd._capi import MgError
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    with DeviceHierarchy.synthetic(2, 1, 3, c=8, mu1=2, mu2=2) as dev:
+        with pytest.raises(MgError):
+            dev.time_kernel("jacobi2", 3, 1)
+    with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=2, mu2=2) as dev:          # 129^3 < fuse_min_rows
+        with pytest.raises(MgError):
+            dev.time_kernel("jacobi2", 4, 1)
+        assert dev.time_kernel("jacobi2!", 4, 1) > 0.0
+        dev.set_tuning("fuse_min_rows", 0)
+        assert dev.time_kernel("jacobi2", 4, 1) > 0.0
