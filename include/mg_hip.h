@@ -159,6 +159,8 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
  *     "fuse_classes"       that pass reads one class byte per row instead of the 32-byte row where the level has
  *                          row classes (1); bit-identical either way
+ *     "class_sweeps"       the one-sweep kernels (residual, single sweeps, SpMV, Gauss-Seidel colours) read the class
+ *                          byte too where the level has row classes (1); bit-identical either way
  *     "fuse_shape"         launch shape of the class-coded pass: 0 = 8 waves x 2 grid lines, 1 = 12 waves x 2 lines,
  *                          2 = 16 waves x 1 line, 3 = 8 waves x 3 lines (1)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)

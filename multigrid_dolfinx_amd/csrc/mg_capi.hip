@@ -219,6 +219,7 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
+    int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     DirectSolver direct;
@@ -463,6 +464,28 @@ void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned
         hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
 }
 
+template <int R, bool NT>
+void launch_sdia_cls_rn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (mode == MODE_JACOBI && finest)
+        hipLaunchKernelGGL((sdia_cls_jacobi_finest<R, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_RESIDUAL)
+        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_JACOBI)
+        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (mode == MODE_GS)
+        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else if (dot)
+        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
+template <int R>
+void launch_sdia_cls_r(int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (nt) launch_sdia_cls_rn<R, true>(mode, dot, finest, a, grid, s);
+    else launch_sdia_cls_rn<R, false>(mode, dot, finest, a, grid, s);
+}
+
 template <int R>
 void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
     switch (WU) {
@@ -533,6 +556,18 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
         const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
+        if (L.cls && c->class_sweeps) {
+            // the rows through their classes: 25 instead of 56 bytes per row (mg_kernels.hip.h, sdia_cls_body)
+            a.cls = L.cls + L.cls_lead; a.ctab = L.ctab;
+            switch (L.R) {
+                case 1: launch_sdia_cls_r<1>(mode, dot, nt, finest, a, grid, c->stream); break;
+                case 2: launch_sdia_cls_r<2>(mode, dot, nt, finest, a, grid, c->stream); break;
+                case 4: launch_sdia_cls_r<4>(mode, dot, nt, finest, a, grid, c->stream); break;
+                default: return fail("unsupported rows_per_lane");
+            }
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         switch (L.R) {
             case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
             case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
@@ -1737,6 +1772,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_shape") {
         if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
+    } else if (k == "class_sweeps") {
+        c->class_sweeps = value != 0;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;
     } else if (k == "fuse_nontemporal") {

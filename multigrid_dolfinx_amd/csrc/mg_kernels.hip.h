@@ -139,6 +139,9 @@ struct EllArgs {
     unsigned strip_bmax;    // blocks (4 slices each) in the widest strip
     unsigned ps4;           // blocks per pseudo-plane
     unsigned kp;            // pseudo-planes
+    // row classes (sdia_cls_apply): class of row r = cls[r] (row-based, zero-padded), entries in ctab[class][4]
+    const unsigned char* cls;
+    const double* ctab;
 };
 
 // ---- XCD strip traversal ----------------------------------------------------------------------
@@ -402,6 +405,79 @@ __global__ __launch_bounds__(BLOCK) void sdia_apply(EllArgs a) {
 template <int WU, int R, bool NT>
 __global__ __launch_bounds__(BLOCK) void sdia_jacobi_finest(EllArgs a) {
     sdia_body<WU, R, MODE_JACOBI, false, NT>(a);
+}
+
+// ---- symmetric diagonal storage read through row classes ------------------------------------------
+// Where a level has row classes (mg_jacobi2.hip.h: at most 255 distinct stored rows, bit for bit), the one-sweep
+// kernels need not stream the 32-byte rows either: one class byte per row, the entries from a 256 x 4 table that
+// every block copies into LDS (8 KB, an L2 hit).  Same entries, same order, same results as sdia_body; per row and
+// sweep 1 (class) + 8 (x) + 8 (f) + 8 (out) = 25 B instead of 56 B.  All four modes (residual, Jacobi, SpMV[+dot],
+// Gauss-Seidel colour); seven-point rows only (WU = 4: classes exist for nothing else).
+template <int R, int MODE, bool DOT, bool NT>
+__device__ __forceinline__ void sdia_cls_body(const EllArgs& a) {
+    __shared__ double sT[256 * 4];
+    if (a.done_flag && *a.done_flag) return;
+    constexpr int S = WAVE * R, WU = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int64_t sl;
+    if (a.strip_ns) {
+        const int64_t first = strip_block(a, blockIdx.x);
+        if (!DOT && first < 0) return;
+        sl = first < 0 ? a.nslices : first + wave;
+    } else {
+        sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    }
+    for (int i = threadIdx.x; i < 256 * 4; i += BLOCK) sT[i] = a.ctab[i];
+    __syncthreads();
+    double dot = 0.0;
+    if (sl < a.nslices) {
+        const int64_t slice = a.slice0 + sl;
+        const int64_t row = slice * S + (int64_t)lane * R;
+        const double* xrow = a.x + a.lead + row;
+        const unsigned char* crow = a.cls + row;
+        int own[R], low[WU][R];
+        DVecU<R> xl[WU], xu[WU];
+#pragma unroll
+        for (int r = 0; r < R; ++r) own[r] = crow[r];
+#pragma unroll
+        for (int c = 1; c < WU; ++c) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) low[c][r] = crow[r - a.up[c]];
+            xl[c] = *reinterpret_cast<const DVecU<R>*>(xrow - a.up[c]);
+            xu[c] = *reinterpret_cast<const DVecU<R>*>(xrow + a.up[c]);
+        }
+        const DVec<R> x0 = *reinterpret_cast<const DVec<R>*>(xrow);
+        double acc[R], diag[R], xr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = 0.0;
+#pragma unroll
+            for (int c = WU - 1; c >= 1; --c) acc[r] = fma(sT[4 * low[c][r] + c], xl[c].d[r], acc[r]);
+            const double* const t = sT + 4 * own[r];
+            xr[r] = x0.d[r];
+            diag[r] = t[0] != 0.0 ? t[0] : 1.0;
+            acc[r] = fma(t[0], xr[r], acc[r]);
+#pragma unroll
+            for (int c = 1; c < WU; ++c) acc[r] = fma(t[c], xu[c].d[r], acc[r]);
+        }
+        tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
+    }
+    if (DOT) {
+        const double t = block_sum(dot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+    }
+}
+
+template <int R, int MODE, bool DOT, bool NT>
+__global__ __launch_bounds__(BLOCK) void sdia_cls_apply(EllArgs a) {
+    sdia_cls_body<R, MODE, DOT, NT>(a);
+}
+
+// (its own symbol for the finest level's Jacobi sweep, like sdia_jacobi_finest)
+template <int R, bool NT>
+__global__ __launch_bounds__(BLOCK) void sdia_cls_jacobi_finest(EllArgs a) {
+    sdia_cls_body<R, MODE_JACOBI, false, NT>(a);
 }
 
 struct SdiaArgs {

@@ -897,3 +897,38 @@ def test_3d_cycles_converge_to_the_direct_solution():
     assert np.all(res[1:] < res[:-1]) or res[-1] <= 1e-13 * np.linalg.norm(f)
     assert res[-1] <= 1e-10 * np.linalg.norm(f), res[-1] / np.linalg.norm(f)
     assert np.linalg.norm(v - u) <= 1e-9 * np.linalg.norm(u)
+
+
+def test_one_sweep_kernels_through_row_classes_are_bit_identical():
+    """`class_sweeps`: residual, single Jacobi sweeps, red-black Gauss-Seidel colours and the SpMV + dot of the PCG /
+    quadratic form read one class byte per row instead of the row where a level has row classes.  Same entries in the
+    same order: bit-identical to the plain symmetric-diagonal kernels, for every rows-per-lane setting."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(3)
+    for R in (1, 2, 4):
+        outs = []
+        for cs in (0, 1):
+            with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=3, mu2=3, rows_per_lane=R, fuse_sweeps=0, class_sweeps=cs,
+                                           coarse_direct=0) as dev:                     # PCG coarsest solve: SpMV + dot
+                n = dev.level_info(4)["n_global"]
+                assert dev.level_info(4)["row_classes"] > 0
+                if not outs:
+                    v_in, f_in = rng.standard_normal(n), rng.standard_normal(n)
+                got = []
+                dev.set_vector(4, "v", v_in)
+                dev.set_vector(4, "f", f_in)
+                dev.smooth(4, 3)
+                got.append(dev.get_vector(4, "v"))
+                dev.residual(4)
+                got.append(dev.get_vector(4, "r"))
+                got.append(np.array([dev.quadratic_form(4, "v")]))
+                dev.zero_vector(4, "v")
+                got.append(np.asarray(dev.vcycle(4, 2, residuals=True)))
+                got.append(dev.get_vector(4, "v"))
+                dev.set_params(2, 2, 1.0, smoother="rbgs")
+                dev.zero_vector(4, "v")
+                dev.vcycle(4, 1)
+                got.append(dev.get_vector(4, "v"))
+                outs.append(got)
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b), R
