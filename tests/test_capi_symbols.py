@@ -46,3 +46,16 @@ def test_missing_library_raises(monkeypatch):
     monkeypatch.setattr(_capi, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
     with pytest.raises(_capi.MgError):
         _capi.load()
+
+
+def test_every_tuning_key_is_documented_in_the_header():
+    """`mg_set_tuning` takes its keys as strings: the header is their only documentation.  Every key the library
+    accepts must be listed there and every key listed there must be accepted."""
+    src = open(os.path.join(ROOT, "multigrid_dolfinx_amd", "csrc", "mg_capi.hip")).read()
+    body = src[src.index("int mg_set_tuning("):]
+    body = body[:body.index("\nnamespace {")]
+    accepted = set(re.findall(r'k == "([a-z_0-9]+)"', body))
+    header = open(os.path.join(ROOT, "include", "mg_hip.h")).read()
+    block = header[header.index("Tuning and format knobs"):header.index("int mg_set_tuning")]
+    documented = set(re.findall(r'^\s*\*\s+"([a-z_0-9]+)"', block, flags=re.M))
+    assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
