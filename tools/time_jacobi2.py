@@ -14,7 +14,7 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=2, mu2=2) as dev:
     out["rows"] = n
     out["jacobi_ms"] = dev.time_kernel("jacobi", hi, reps)
     print(out, flush=True)
-    for shape in (0, 1, 2, 3):
+    for shape in ([int(os.environ['J2_SHAPE'])] if 'J2_SHAPE' in os.environ else (0, 1, 2, 3)):
         for seg in ([int(a) for a in sys.argv[3:]] or (0, 1, 3, 4, 6, 8, 11, 13, 16)):
             for nt in (0,):
                 dev.set_tuning("fuse_shape", shape)
