@@ -998,6 +998,9 @@ int residual_restrict_fused(mg_context* c, int level) {
     if (F.sdia) {
         a.vals = F.dvals; a.W = F.wu; a.coded = 2; a.mlead = F.mlead;
         for (int t = 0; t < 8; ++t) a.up[t] = F.up[t];
+        if (F.cls && c->class_sweeps && F.wu == 4) {
+            a.coded = 3; a.cls = F.cls + F.cls_lead; a.ctab = F.ctab;
+        }
     }
     hipLaunchKernelGGL(residual_inject, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, a);
     HIP_TRY(hipGetLastError());

@@ -910,10 +910,13 @@ struct FusedRestrictArgs {
     const double* x;        // fine iterate, base of storage
     const double* f;        // fine right-hand side, row-based
     double* fc;             // coarse right-hand side, base of storage
-    int W, R, coded;        // coded: 0 int32 columns, 1 offset codes, 2 symmetric diagonals (W = WU)
+    int W, R, coded;        // coded: 0 int32 columns, 1 offset codes, 2 symmetric diagonals (W = WU), 3 the same
+                            // through row classes (cls row-based, ctab[class][4]; seven-point rows)
     int up[8];
     int64_t mlead;
     Grid gc, gf;
+    const unsigned char* cls;
+    const double* ctab;
 };
 
 __global__ void residual_inject(FusedRestrictArgs a) {
@@ -932,7 +935,14 @@ __global__ void residual_inject(FusedRestrictArgs a) {
     const int64_t slice = row / S, within = row % S;
     const size_t base = (size_t)slice * a.W * S + within;
     double acc = 0.0;
-    if (a.coded == 2) {
+    if (a.coded == 3) {
+        const unsigned char* crow = a.cls + row;
+        const double* xrow = a.x + a.gf.lead + row;
+        for (int c = 3; c >= 1; --c) acc = fma(a.ctab[4 * crow[-a.up[c]] + c], xrow[-a.up[c]], acc);
+        const double* t = a.ctab + 4 * crow[0];
+        acc = fma(t[0], xrow[0], acc);
+        for (int c = 1; c < 4; ++c) acc = fma(t[c], xrow[a.up[c]], acc);
+    } else if (a.coded == 2) {
         const int64_t m = row + a.mlead;
         const double* xrow = a.x + a.gf.lead + row;
         for (int c = a.W - 1; c >= 1; --c) {

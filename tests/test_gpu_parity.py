@@ -541,7 +541,7 @@ def test_fused_residual_injection_is_bit_identical(dim, lo, hi, c):
     bag = poisson.make_hierarchy(dim, lo, hi, c=c, mu1=3, mu2=3, seed=12)
     gi = {l: L.grid_index for l, L in bag.levels.items()}
     f = bag.b_dict[hi]
-    for kw in (dict(), dict(symmetric_storage=0), dict(offset_codes=0)):
+    for kw in (dict(), dict(class_sweeps=0), dict(symmetric_storage=0), dict(offset_codes=0)):
         outs = []
         for fused in (1, 0):
             with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, **kw) as dev:
