@@ -488,12 +488,17 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     auto ldd = [](const char* b, unsigned e, int d) -> double { return *reinterpret_cast<const double*>(b + (e << 3) + d * 8); };
     auto ldc = [](const char* b, unsigned e, int d) -> int { return *reinterpret_cast<const unsigned char*>(b + e + d); };
 
-    int cm[NC], c0[NC], c1[NC], c2[NC];
+    // classes of the cell in planes k-1, k, k+1: one byte each of cpk (k-1 lowest); c2: plane k+2, in flight
+    unsigned cpk[NC];
+    int c1[NC], c2[NC];
+    auto cls_m = [&](int c) -> int { return (int)(cpk[c] & 255u); };
+    auto cls_0 = [&](int c) -> int { return (int)((cpk[c] >> 8) & 255u); };
+    auto cls_1 = [&](int c) -> int { return (int)((cpk[c] >> 16) & 255u); };
     double f0[NC], f1[NC], f2[NC], wm[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], vd[NC];
     double hxl[LPW], hyv[2];
     int hxc[LPW], hyc[2];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { f0[c] = wm[c] = w0[c] = w1[c] = 0.0; cm[c] = 0; }
+    for (int c = 0; c < NC; ++c) { f0[c] = wm[c] = w0[c] = w1[c] = 0.0; }
 #pragma unroll
     for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
     hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
@@ -579,8 +584,10 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     load_x(z0 - 2, true, va);
     load_x(z0 - 1, true, vb);
     load_x(z0, true, vc);
-    load_c(z0 - 2, c0);
+    load_c(z0 - 2, c2);
     park(z0 - 1, vb, c1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cpk[c] = ((unsigned)c2[c] << 8) | ((unsigned)c1[c] << 16);
     __syncthreads();
 
     for (int k = z0 - 2; k < z1; ++k) {
@@ -596,8 +603,8 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int iv = lvof(c), iw = lwof(c);
-            const double s0 = sT[4 * c0[c] + 3];
-            const double* const t1 = sT + 4 * c1[c];
+            const double s0 = sT[4 * cls_0(c) + 3];
+            const double* const t1 = sT + 4 * cls_1(c);
             // first sweep on plane k+1
             double acc = 0.0;
             acc = fma(s0, va[c], acc);                                          // -P
@@ -607,7 +614,7 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
             acc = fma(t1[1], x1[iv + 1], acc);                                  // +1
             acc = fma(t1[2], x1[iv + PV], acc);                                 // +nx
             acc = fma(t1[3], vc[c], acc);                                       // +P
-            const double o = vb[c] + sCF[c1[c]] * (f1[c] - acc);
+            const double o = vb[c] + sCF[cls_1(c)] * (f1[c] - acc);
             const int64_t r1 = rowof(c) + o1;
             w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
             v1w[iw] = w1[c];
@@ -615,16 +622,16 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
                 const int64_t r0 = r1 - a.P;
                 if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi) {
                     // second sweep on plane k: its in-plane neighbours were written a step ago
-                    const double* const t0 = sT + 4 * c0[c];
+                    const double* const t0 = sT + 4 * cls_0(c);
                     double ac2 = 0.0;
-                    ac2 = fma(sT[4 * cm[c] + 3], wm[c], ac2);                   // -P
+                    ac2 = fma(sT[4 * cls_m(c) + 3], wm[c], ac2);                // -P
                     ac2 = fma(sT[4 * cp0[iv - PV] + 2], v1r[iw - EX], ac2);     // -nx
                     ac2 = fma(sT[4 * cp0[iv - 1] + 1], v1r[iw - 1], ac2);       // -1
                     ac2 = fma(t0[0], w0[c], ac2);
                     ac2 = fma(t0[1], v1r[iw + 1], ac2);                         // +1
                     ac2 = fma(t0[2], v1r[iw + EX], ac2);                        // +nx
                     ac2 = fma(s0, w1[c], ac2);                                  // +P
-                    a.out[r0] = w0[c] + sCF[c0[c]] * (f0[c] - ac2);
+                    a.out[r0] = w0[c] + sCF[cls_0(c)] * (f0[c] - ac2);
                 }
                 if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
             }
@@ -632,7 +639,7 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
         park(k + 2, vc, c2);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            cm[c] = c0[c]; c0[c] = c1[c]; c1[c] = c2[c];
+            cpk[c] = (cpk[c] >> 8) | ((unsigned)c2[c] << 16);
             f0[c] = f1[c]; f1[c] = f2[c]; wm[c] = w0[c]; w0[c] = w1[c];
             va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
         }
