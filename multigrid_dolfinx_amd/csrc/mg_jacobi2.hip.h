@@ -588,11 +588,13 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     park(z0 - 1, vb, c1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) cpk[c] = ((unsigned)c2[c] << 8) | ((unsigned)c1[c] << 16);
+    // the loads of a step are issued BEFORE the barrier that ends the step before it: the time the waves spend at
+    // the barrier is flight time too
+    load_plane(z0, z0 <= z1, c2, f2);
+    load_x(z0 + 1, z0 + 1 <= z1 + 1, vd);
     __syncthreads();
 
     for (int k = z0 - 2; k < z1; ++k) {
-        load_plane(k + 2, k + 2 <= z1, c2, f2);
-        load_x(k + 3, k + 3 <= z1 + 1, vd);
 
         const unsigned char* const cp1 = sC + slot3(k + 1) * CS;      // classes of plane k+1
         const unsigned char* const cp0 = sC + slot3(k) * CS;          // classes of plane k
@@ -642,6 +644,10 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
             cpk[c] = (cpk[c] >> 8) | ((unsigned)c2[c] << 16);
             f0[c] = f1[c]; f1[c] = f2[c]; wm[c] = w0[c]; w0[c] = w1[c];
             va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+        }
+        if (k + 1 < z1) {
+            load_plane(k + 3, k + 3 <= z1, c2, f2);
+            load_x(k + 4, k + 4 <= z1 + 1, vd);
         }
         __syncthreads();
     }
