@@ -143,7 +143,7 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "offset_codes"       0 keeps int32 column indices (1)
  *     "symmetric_storage"  0 keeps lower entries even for bit-for-bit symmetric matrices (1)
  *     "require_diagonal"   0 accepts operators without a diagonal, e.g. D^-1 R for mg_smooth_split (1)
- *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 7-point levels (1)
+ *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
  *   any time:
  *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)
  *     "strip_slices"       slices per XCD strip, 0 = chunked map only (64)
@@ -163,6 +163,11 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *                          byte too where the level has row classes (1); bit-identical either way
  *     "fuse_shape"         launch shape of the class-coded pass: 0 = 8 waves x 2 grid lines, 1 = 12 waves x 2 lines,
  *                          2 = 16 waves x 1 line, 3 = 8 waves x 3 lines (1)
+ *     "fuse_even"          1 = the tile columns of the class-coded pass are equally wide, as narrow as covers the grid;
+ *                          0 = always 124 cells, the last column nearly empty (0: measured faster); bit-identical
+ *     "fuse_wi"            experiments: that width given directly (0 = chosen per level as above)
+ *     "fuse_xcd_chunk"     consecutive tiles of that pass given to one XCD at a time (32)
+ *     "cls_blocks_per_cu"  persistent blocks per CU of the one-sweep class kernels (4)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
  *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)
@@ -174,9 +179,9 @@ int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, i
                   int64_t* nnz_stored, int64_t* nnz_nonzero, int* ell_width, int* replicated,
                   int* offset_codes /* 0 = int32 columns; > 0 = offset codes (number of distinct
                                        offsets); < 0 = symmetric diagonal storage (-stored diagonals) */);
-/* Number of distinct stored rows (the all-zero row included) when the level's symmetric diagonal storage also
- * carries one class byte per row for the two-sweep pass, 0 when it does not (more than 255 distinct rows, another
- * format, "row_classes" 0).  No reference counterpart: storage detail of jacobiRelaxation (multigrid.py:223-228). */
+/* Number of distinct full rows (the all-zero row included) when the level's symmetric diagonal storage also
+ * carries one class byte per row (the row's five or seven entries, bit for bit, from a table), 0 when it does not
+ * (more than 255 distinct rows, another format, "row_classes" 0).  No reference counterpart: storage detail of jacobiRelaxation (multigrid.py:223-228). */
 int mg_level_row_classes(mg_handle h, int level, int* classes);
 
 /* ---- vectors ---------------------------------------------------------------------------

@@ -141,10 +141,12 @@ struct Level {
     int wu = 0;
     int up[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t mlead = 0, mslices = 0;
-    // row classes of the symmetric diagonal storage (mg_jacobi2.hip.h): one byte per stored row + a 256 x 4 table
+    // row classes of the symmetric diagonal storage (mg_jacobi2.hip.h): one byte per row + a 256 x 8 table of full rows
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
     int ncls = 0;
+    int cmain = 0;                          // the most frequent class and its entries (passed to the kernels by value)
+    double cm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t cls_lead = 0, cls_rows = 0;     // cls[row + cls_lead], zero padding of cls_lead entries on both sides
     double* dinv = nullptr;
     DVector v, v2, f, err, ftrue;
@@ -222,6 +224,10 @@ struct mg_context {
     int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
+    int fuse_wi = 0;                // experiments: cells per tile line with a second sweep (0: chosen per level)
+    int fuse_even = 0;              // all tile columns of the class-coded pass equally wide (measured slower: more full tiles, same bytes)
+    int fuse_xcd_chunk = 32;        // consecutive tiles of that pass per XCD at a time
+    int cls_blocks_per_cu = 4;      // persistent blocks of the one-sweep class kernels (72 VGPRs, 94 SGPRs admit 7)
     DirectSolver direct;
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
@@ -389,7 +395,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.offsets, 256);
     dev_free(c, L.dvals, (size_t)L.mslices * (L.wu > 0 ? L.wu : 1) * (WAVE * L.R));
     dev_free(c, L.cls, (size_t)L.cls_rows);
-    dev_free(c, L.ctab, 256 * 4);
+    dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
     L.coded = false;
     L.rb_ok = false;
@@ -464,26 +470,31 @@ void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned
         hipLaunchKernelGGL((sdia_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
 }
 
-template <int R, bool NT>
-void launch_sdia_cls_rn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+template <int WU, int R, bool NT>
+void launch_sdia_cls_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
     if (mode == MODE_JACOBI && finest)
-        hipLaunchKernelGGL((sdia_cls_jacobi_finest<R, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_jacobi_finest<WU, R, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_RESIDUAL)
-        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_apply<WU, R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_JACOBI)
-        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_apply<WU, R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (mode == MODE_GS)
-        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_apply<WU, R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else if (dot)
-        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_apply<WU, R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((sdia_cls_apply<R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sdia_cls_apply<WU, R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a);
 }
 
 template <int R>
-void launch_sdia_cls_r(int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
-    if (nt) launch_sdia_cls_rn<R, true>(mode, dot, finest, a, grid, s);
-    else launch_sdia_cls_rn<R, false>(mode, dot, finest, a, grid, s);
+void launch_sdia_cls_r(int WU, int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+    if (WU == 3) {
+        if (nt) launch_sdia_cls_wrn<3, R, true>(mode, dot, finest, a, grid, s);
+        else launch_sdia_cls_wrn<3, R, false>(mode, dot, finest, a, grid, s);
+    } else {
+        if (nt) launch_sdia_cls_wrn<4, R, true>(mode, dot, finest, a, grid, s);
+        else launch_sdia_cls_wrn<4, R, false>(mode, dot, finest, a, grid, s);
+    }
 }
 
 template <int R>
@@ -557,12 +568,20 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         const bool nt = c->nontemporal != 0;
         const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
         if (L.cls && c->class_sweeps) {
-            // the rows through their classes: 25 instead of 56 bytes per row (mg_kernels.hip.h, sdia_cls_body)
-            a.cls = L.cls + L.cls_lead; a.ctab = L.ctab;
+            // the rows through their classes: 25 instead of 56 bytes per row (mg_kernels.hip.h, sdia_cls_body);
+            // persistent blocks (8 per CU, a multiple of 8 so that a block's groups stay on one XCD's share)
+            a.cls = L.cls + L.cls_lead; a.ctab = L.ctab; a.ncls = L.ncls; a.cmain = L.cmain;
+            for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+            a.nvirt = grid;
+            // (with the dot product one group per block, as the other formats have it: the partial sums and with them
+            //  the rounding of the result do not depend on the format)
+            const unsigned resident = (unsigned)c->cls_blocks_per_cu * (unsigned)std::max(1, c->prop.multiProcessorCount);
+            if (!dot) grid = std::min(grid, resident);
+            if (grid_out) *grid_out = grid;
             switch (L.R) {
-                case 1: launch_sdia_cls_r<1>(mode, dot, nt, finest, a, grid, c->stream); break;
-                case 2: launch_sdia_cls_r<2>(mode, dot, nt, finest, a, grid, c->stream); break;
-                case 4: launch_sdia_cls_r<4>(mode, dot, nt, finest, a, grid, c->stream); break;
+                case 1: launch_sdia_cls_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
+                case 2: launch_sdia_cls_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
+                case 4: launch_sdia_cls_r<4>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
                 default: return fail("unsupported rows_per_lane");
             }
             HIP_TRY(hipGetLastError());
@@ -738,7 +757,7 @@ constexpr int kJ2Lines = 16;        // grid lines per tile (8 waves x 2)
 //     (planes per piece + ~2.5 plane-times of warm-up) -- which is what measured best on 1025^3 (8 pieces);
 //   slabs: zb short (the planes whose once-relaxed values travel to the neighbours, plus one), so that the
 //     boundary work that the exchanges wait for is small, the interior cut by the same cost model.
-struct J2Plan { int ntx, nty, nseg, zb, seglen; };
+struct J2Plan { int ntx, nty, nseg, zb, seglen, wi; };
 
 // grid lines per tile: 16 for the plain pass; the class-coded pass has shapes with 16 and 32 ("fuse_shape")
 int jacobi2_lines(const mg_context* c, const Level& L) {
@@ -752,6 +771,16 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     const int lines = jacobi2_lines(c, L);
     p.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
     p.nty = (L.g.ny + lines - 3) / (lines - 2);
+    if (L.cls && c->fuse_classes) {
+        // class-coded pass: the x ring is part of the tile (124 cells with a second sweep at most), and all tile
+        // columns have the same width, the smallest that covers the grid ("fuse_even" 0: always the widest)
+        p.ntx = (L.g.nx + J2_EX - 5) / (J2_EX - 4);
+        p.wi = c->fuse_even ? (L.g.nx + p.ntx - 1) / p.ntx : J2_EX - 4;
+        if (c->fuse_wi > 0) {                                       // experiments: a given width
+            p.wi = std::min(J2_EX - 4, std::max(8, c->fuse_wi));
+            p.ntx = (L.g.nx + p.wi - 1) / p.wi;
+        }
+    }
     const int64_t ntile = (int64_t)p.ntx * p.nty;
     const int nk = L.g.nk;
     const int64_t cus = std::max(1, c->prop.multiProcessorCount);      // one resident workgroup per CU
@@ -793,10 +822,12 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
 template <int NW, int LPW>
 int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
-    if (items >= ((int64_t)1 << 31) - 512) return fail("too many tiles");
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
     J2Args b = a;
     b.nitems = (unsigned)items;
-    const unsigned grid = (unsigned)((items + 255) / 256) * 256u;
+    b.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
+    const int64_t group = 8 * (int64_t)b.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
     constexpr size_t lds = j2c_lds_bytes<NW, LPW>();
     void (*const kern[2])(J2Args) = {sdia_jacobi2c<NW, LPW>, sdia_jacobi2c_finest<NW, LPW>};
     MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
@@ -844,6 +875,8 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     if (L.cls && c->fuse_classes) {
         a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead;
+        a.ncls = L.ncls; a.cmain = L.cmain; a.wi = plan.wi;
+        for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
         switch (c->fuse_shape) {
             case 0: return launch_jacobi2c_t<8, 2>(c, a, n, finest);       // 16 lines, 512 threads
             case 2: return launch_jacobi2c_t<16, 1>(c, a, n, finest);      // 16 lines, 1024 threads
@@ -998,7 +1031,7 @@ int residual_restrict_fused(mg_context* c, int level) {
     if (F.sdia) {
         a.vals = F.dvals; a.W = F.wu; a.coded = 2; a.mlead = F.mlead;
         for (int t = 0; t < 8; ++t) a.up[t] = F.up[t];
-        if (F.cls && c->class_sweeps && F.wu == 4) {
+        if (F.cls && c->class_sweeps) {
             a.coded = 3; a.cls = F.cls + F.cls_lead; a.ctab = F.ctab;
         }
     }
@@ -1397,36 +1430,39 @@ int encode_level(mg_context* c, Level& L) {
     return 0;
 }
 
-// Row classes for the two-sweep pass (mg_jacobi2.hip.h, "row classes"): a dictionary of the level's distinct stored
-// rows, built and verified on the device; levels with more than 255 distinct non-zero rows go without.
+// Row classes (mg_jacobi2.hip.h, "row classes"): a dictionary of the level's distinct FULL rows (five- or seven-point),
+// built and verified on the device; levels with more than 255 distinct non-zero rows go without.
 int build_row_classes(mg_context* c, Level& L) {
-    if (!c->use_classes || !L.sdia || L.wu != 4) return 0;
-    const int64_t S = (int64_t)WAVE * L.R, mrows = L.mslices * S;
-    // scratch: hash tags | slot values | count, flag, slot_class[CLS_SLOTS]
+    if (!c->use_classes || !L.sdia || (L.wu != 3 && L.wu != 4)) return 0;
+    // scratch: hash tags | slot values | count, flag, slot_class[CLS_SLOTS], hist[256]
     struct Scratch {
         char* p = nullptr;
         ~Scratch() { if (p) (void)hipFree(p); }
     } scratch;
-    const size_t tag_bytes = CLS_SLOTS * sizeof(unsigned long long), val_bytes = (size_t)CLS_SLOTS * 4 * sizeof(double);
-    const size_t int_bytes = (2 + CLS_SLOTS) * sizeof(int);
+    const size_t tag_bytes = CLS_SLOTS * sizeof(unsigned long long), val_bytes = (size_t)CLS_SLOTS * CLS_W * sizeof(double);
+    const size_t int_bytes = (2 + CLS_SLOTS + 256) * sizeof(int);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch.p), tag_bytes + val_bytes + int_bytes));
     HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + val_bytes + int_bytes, c->stream));
-    struct { unsigned long long* p; } tags{reinterpret_cast<unsigned long long*>(scratch.p)};
-    struct { double* p; } svals{reinterpret_cast<double*>(scratch.p + tag_bytes)};
-    struct { int* p; } ints{reinterpret_cast<int*>(scratch.p + tag_bytes + val_bytes)};
+    int* const ints = reinterpret_cast<int*>(scratch.p + tag_bytes + val_bytes);
     // padded like the vectors (vec_reach) so that the pass can read whole tiles around the level unpredicated
     const int64_t cls_lead = ((std::max(L.mlead, vec_reach(L)) + 255) / 256) * 256;
     const int64_t cls_rows = cls_lead + L.nloc + cls_lead + 512;
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
     MG_TRY(dev_alloc(c, &cls, (size_t)cls_rows));
-    MG_TRY(dev_alloc(c, &ctab, 256 * 4));
+    MG_TRY(dev_alloc(c, &ctab, 256 * CLS_W));
     ClsArgs a{};
-    a.dvals = L.dvals; a.mrows = mrows; a.tags = tags.p; a.svals = svals.p; a.count = ints.p; a.flag = ints.p + 1;
-    a.slot_class = ints.p + 2; a.ctab = ctab; a.cls = cls;
-    a.crows = cls_rows; a.cshift = cls_lead - L.mlead;
-    const dim3 grid(blocks_for(mrows, 256)), egrid(blocks_for(cls_rows, 256)), blk(256);
+    a.dvals = L.dvals; a.wu = L.wu; a.nloc = L.nloc; a.mlead = L.mlead;
+    for (int t = 0; t < 4; ++t) a.up[t] = L.up[t];
+    a.tags = reinterpret_cast<unsigned long long*>(scratch.p);
+    a.svals = reinterpret_cast<double*>(scratch.p + tag_bytes);
+    a.count = ints; a.flag = ints + 1; a.slot_class = ints + 2;
+    a.hist = reinterpret_cast<unsigned*>(ints + 2 + CLS_SLOTS);
+    a.ctab = ctab; a.cls = cls; a.crows = cls_rows; a.clead = cls_lead;
+    const dim3 grid(blocks_for(L.nloc, 256)), egrid(blocks_for(cls_rows, 256)), blk(256);
     int h[2] = {0, 0};
+    std::vector<unsigned> hist(256, 0u);
+    std::vector<double> tab(256 * CLS_W, 0.0);
     int rc = [&]() -> int {
         switch (L.R) {
             case 1: hipLaunchKernelGGL(cls_insert<64>, grid, blk, 0, c->stream, a); break;
@@ -1440,16 +1476,22 @@ int build_row_classes(mg_context* c, Level& L) {
             default: hipLaunchKernelGGL(cls_encode<256>, egrid, blk, 0, c->stream, a); break;
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h, ints.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, ints, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hist.data(), a.hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(tab.data(), ctab, 256 * CLS_W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
     }();
     if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass
         dev_free(c, cls, (size_t)cls_rows);
-        dev_free(c, ctab, 256 * 4);
+        dev_free(c, ctab, 256 * CLS_W);
         return rc;
     }
     L.cls = cls; L.ctab = ctab; L.ncls = h[0] + 1; L.cls_lead = cls_lead; L.cls_rows = cls_rows;
+    L.cmain = 0;
+    for (int k = 1; k < L.ncls; ++k)
+        if (L.cmain == 0 || hist[k] > hist[L.cmain]) L.cmain = k;
+    for (int t = 0; t < 8; ++t) L.cm[t] = tab[(size_t)CLS_W * L.cmain + t];
     return 0;
 }
 
@@ -1775,6 +1817,16 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_shape") {
         if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
+    } else if (k == "fuse_xcd_chunk") {
+        if (value < 1 || value > 512) return fail("fuse_xcd_chunk must be in 1..512");
+        c->fuse_xcd_chunk = (int)value;
+    } else if (k == "cls_blocks_per_cu") {
+        if (value < 1 || value > 64) return fail("cls_blocks_per_cu must be in 1..64");
+        c->cls_blocks_per_cu = (int)value;
+    } else if (k == "fuse_wi") {
+        c->fuse_wi = (int)value;
+    } else if (k == "fuse_even") {
+        c->fuse_even = value != 0;
     } else if (k == "class_sweeps") {
         c->class_sweeps = value != 0;
     } else if (k == "fuse_classes") {

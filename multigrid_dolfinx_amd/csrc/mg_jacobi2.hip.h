@@ -37,10 +37,14 @@ struct J2Args {
     int64_t xlo, xhi, slo, st_lo, st_hi, k1_lo, k1_hi;
     double* v1out;          // row-based, may be null (whole levels)
     const double* zero;     // >= 3*S+1 stored zeros (the slack in front of a vector)
-    // row classes (sdia_jacobi2c): cls[row + mlead] indexes ctab[class][4] = (diagonal, +1, +nx, +P entries)
+    // row classes (sdia_jacobi2c): cls[row + clead] indexes ctab[class][CLS_W] = the row's seven entries in column order
     const unsigned char* cls;
     const double* ctab;
     int64_t clead;          // padding in front of cls[]: class of row r is cls[r + clead]
+    int ncls, cmain;        // classes in use (0 .. ncls-1); the most frequent one, whose entries are
+    double cm[8];           // passed by value (scalar registers)
+    int wi;                 // class-coded pass: cells per tile line that get their second sweep (<= 124)
+    unsigned xcd_chunk;     // consecutive work items per XCD at a time (the grid is a multiple of 8 * xcd_chunk)
     int nx, ny, nz;
     // plane segments: 0 = [0, zb), nseg-1 = [nz-zb, nz), the others cut [zb, nz-zb) into pieces of seglen planes;
     // this launch covers the segments seg0, seg0 + seg_stride, ... (nitems / (ntx*nty) of them)
@@ -282,25 +286,31 @@ __device__ __forceinline__ void j2_body(const J2Args& a) {
 // ---- row classes ------------------------------------------------------------------------------
 // On the meshes this path is built for (uniform grids, constant coefficients) the rows of a level's matrix take
 // only a handful of distinct values: the interior stencil, its variants next to a Dirichlet boundary, the
-// identity rows.  When the stored rows (diagonal, +1, +nx, +P entry; the lower entries are those of other rows)
-// take at most 255 distinct non-zero values BIT FOR BIT, the two-sweep pass reads one byte per row -- its class --
-// instead of 32 bytes of matrix, and looks the entries up in a 256 x 4 table kept in LDS: 25 instead of 56 bytes
-// per row and pair of sweeps, with exactly the same arithmetic on exactly the same numbers.  The dictionary is
-// built on the device (hash insert, compaction, encode + bitwise verification); a level with more distinct rows
-// simply keeps the plain pass.
-constexpr int CLS_SLOTS = 4096;
+// identity rows.  When the FULL rows -- the seven entries a(-P) a(-nx) a(-1) a(0) a(+1) a(+nx) a(+P) exactly as
+// sdia_body reads them: the upper ones from the row's own slots, the lower ones from the slots of the rows
+// below -- take at most 255 distinct non-zero values BIT FOR BIT, every kernel that applies the matrix reads one
+// byte per row -- its class -- instead of 32 bytes of matrix and looks the entries up in a table of 8 doubles per
+// class (CLS_W; slot 7 is spare: the kernels keep omega/diagonal there): 25 instead of 56 bytes per row, with exactly
+// the same arithmetic on exactly the same numbers.  A class names the whole row, so no kernel needs a neighbour's
+// class.  The dictionary is built on the device (hash insert, compaction in slot order, encode + bitwise
+// verification of every row against its entry, histogram); a level with more distinct rows simply has no classes.
+// Five-point rows of 2-D levels (stored diagonals {0, +1, +nx}) use the same table with a(-P) = a(+P) = 0.
+constexpr int CLS_SLOTS = 4096;         // (CLS_W = 8 doubles per table row: mg_kernels.hip.h)
 
 struct ClsArgs {
-    const double* dvals;            // symmetric diagonal storage, WU = 4
-    int64_t mrows;                  // rows stored (lead rows included)
+    const double* dvals;            // symmetric diagonal storage
+    int wu;                         // slots per stored row (3: {0,+1,+nx}; 4: {0,+1,+nx,+P})
+    int64_t nloc, mlead;
+    int64_t up[4];                  // positive offsets of the slots (up[0] = 0)
     unsigned long long* tags;       // CLS_SLOTS hash tags, 0 = free
-    double* svals;                  // CLS_SLOTS x 4
+    double* svals;                  // CLS_SLOTS x CLS_W
     int* count;                     // distinct non-zero rows seen
     int* slot_class;                // CLS_SLOTS
-    double* ctab;                   // 256 x 4
-    unsigned char* cls;             // crows: cls[i] is the class of stored row i - cshift (class 0 where there is none)
-    int64_t crows, cshift;
+    double* ctab;                   // 256 x CLS_W
+    unsigned char* cls;             // crows: cls[i] is the class of row i - clead (class 0 outside the level)
+    int64_t crows, clead;
     int* flag;                      // set when a row does not match its dictionary entry
+    unsigned* hist;                 // 256: rows per class
 };
 
 __device__ __forceinline__ unsigned long long cls_mix(unsigned long long x) {
@@ -308,27 +318,40 @@ __device__ __forceinline__ unsigned long long cls_mix(unsigned long long x) {
     return x;
 }
 
-template <int S> __device__ __forceinline__ void cls_row(const ClsArgs& a, int64_t m, unsigned long long (&b)[4]) {
-    const size_t base = (size_t)(m / S) * (4 * S) + (size_t)(m % S);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = (unsigned long long)__double_as_longlong(a.dvals[base + (size_t)c * S]);
+// the seven entries of row `row` (0 <= row < nloc) in ascending column order
+template <int S> __device__ __forceinline__ void cls_row(const ClsArgs& a, int64_t row, unsigned long long (&b)[7]) {
+    const int64_t m = row + a.mlead;
+    auto at = [&](int64_t mm, int c) -> unsigned long long {
+        return (unsigned long long)__double_as_longlong(a.dvals[((size_t)(mm / S) * a.wu + c) * S + (size_t)(mm % S)]);
+    };
+    b[3] = at(m, 0);
+    b[4] = at(m, 1); b[2] = at(m - a.up[1], 1);
+    b[5] = at(m, 2); b[1] = at(m - a.up[2], 2);
+    b[6] = a.wu > 3 ? at(m, 3) : 0ull;
+    b[0] = a.wu > 3 ? at(m - a.up[3], 3) : 0ull;
 }
 
-__device__ __forceinline__ unsigned long long cls_hash(const unsigned long long (&b)[4]) {
-    unsigned long long h = cls_mix(b[0] + 0x9e3779b97f4a7c15ull);
-    h = cls_mix(h ^ (b[1] + 0x3c6ef372fe94f82bull));
-    h = cls_mix(h ^ (b[2] + 0xdaa66d2c7ddf743full));
-    h = cls_mix(h ^ (b[3] + 0x78dde6e5fd29f054ull));
+__device__ __forceinline__ bool cls_zero(const unsigned long long (&b)[7]) {
+    unsigned long long o = 0ull;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o |= b[c];                    // bit patterns: a -0.0 entry makes its own class
+    return o == 0ull;
+}
+
+__device__ __forceinline__ unsigned long long cls_hash(const unsigned long long (&b)[7]) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) h = cls_mix(h ^ (b[c] + 0x3c6ef372fe94f82bull * (unsigned long long)(c + 1)));
     return h ? h : 1ull;
 }
 
 template <int S>
 __global__ void cls_insert(ClsArgs a) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= a.mrows) return;
-    unsigned long long b[4];
-    cls_row<S>(a, m, b);
-    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) return;          // class 0: the all-zero row
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    unsigned long long b[7];
+    cls_row<S>(a, row, b);
+    if (cls_zero(b)) return;                                  // class 0: the all-zero row
     const unsigned long long h = cls_hash(b);
     unsigned s = (unsigned)h & (CLS_SLOTS - 1);
     for (int probe = 0; probe < CLS_SLOTS; ++probe) {
@@ -340,7 +363,7 @@ __global__ void cls_insert(ClsArgs a) {
         const unsigned long long old = atomicCAS(a.tags + s, 0ull, h);
         if (old == 0ull) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a.svals[4 * s + c] = __longlong_as_double((long long)b[c]);
+            for (int c = 0; c < 7; ++c) a.svals[CLS_W * s + c] = __longlong_as_double((long long)b[c]);
             atomicAdd(a.count, 1);
             return;
         }
@@ -352,81 +375,110 @@ __global__ void cls_insert(ClsArgs a) {
 // one thread: classes 1, 2, ... in slot order (deterministic for a given matrix)
 __global__ void cls_assign(ClsArgs a) {
     if (blockIdx.x || threadIdx.x) return;
-    for (int c = 0; c < 4; ++c) a.ctab[c] = 0.0;
+    for (int c = 0; c < CLS_W; ++c) a.ctab[c] = 0.0;
     int id = 1;
     for (int s = 0; s < CLS_SLOTS; ++s) {
         a.slot_class[s] = 0;
         if (a.tags[s] && id < 256) {
             a.slot_class[s] = id;
-            for (int c = 0; c < 4; ++c) a.ctab[4 * id + c] = a.svals[4 * s + c];
+            for (int c = 0; c < 7; ++c) a.ctab[CLS_W * id + c] = a.svals[CLS_W * s + c];
+            a.ctab[CLS_W * id + 7] = 0.0;
             ++id;
         }
     }
     for (; id < 256; ++id)
-        for (int c = 0; c < 4; ++c) a.ctab[4 * id + c] = 0.0;
+        for (int c = 0; c < CLS_W; ++c) a.ctab[CLS_W * id + c] = 0.0;
 }
 
 template <int S>
-__global__ void cls_encode(ClsArgs a) {
+__global__ __launch_bounds__(256) void cls_encode(ClsArgs a) {
+    __shared__ unsigned s_hist[256];
+    s_hist[threadIdx.x] = 0u;
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.crows) return;
-    const int64_t m = i - a.cshift;
-    if (m < 0 || m >= a.mrows) { a.cls[i] = 0; return; }
-    unsigned long long b[4];
-    cls_row<S>(a, m, b);
-    if ((b[0] | b[1] | b[2] | b[3]) == 0ull) { a.cls[i] = 0; return; }
-    const unsigned long long h = cls_hash(b);
-    unsigned s = (unsigned)h & (CLS_SLOTS - 1);
-    for (int probe = 0; probe < CLS_SLOTS; ++probe) {
-        const unsigned long long t = a.tags[s];
-        if (t == h) {
-            bool same = true;
+    if (i < a.crows) {
+        const int64_t row = i - a.clead;
+        int id = 0;
+        if (row >= 0 && row < a.nloc) {
+            unsigned long long b[7];
+            cls_row<S>(a, row, b);
+            if (!cls_zero(b)) {
+                const unsigned long long h = cls_hash(b);
+                unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+                bool found = false;
+                for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+                    const unsigned long long t = a.tags[s];
+                    if (t == h) {
+                        bool same = true;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) same = same && (unsigned long long)__double_as_longlong(a.svals[4 * s + c]) == b[c];
-            if (!same || a.slot_class[s] == 0) atomicExch(a.flag, 1);       // hash collision / overflow: no classes
-            a.cls[i] = (unsigned char)a.slot_class[s];
-            return;
+                        for (int c = 0; c < 7; ++c)
+                            same = same && (unsigned long long)__double_as_longlong(a.svals[CLS_W * s + c]) == b[c];
+                        id = a.slot_class[s];
+                        found = same && id != 0;                    // hash collision / overflow: no classes
+                        break;
+                    }
+                    if (t == 0ull) break;
+                    s = (s + 1) & (CLS_SLOTS - 1);
+                }
+                if (!found) { atomicExch(a.flag, 1); id = 0; }
+            }
+            atomicAdd(&s_hist[id], 1u);
         }
-        if (t == 0ull) break;
-        s = (s + 1) & (CLS_SLOTS - 1);
+        a.cls[i] = (unsigned char)id;
     }
-    atomicExch(a.flag, 1);
-    a.cls[i] = 0;
+    __syncthreads();
+    if (s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
 }
 
 // ---- the two-sweep pass on class-coded rows ----------------------------------------------------
 // Same march, same arithmetic as j2_body; per cell and step it loads one class byte, f and x (17 bytes instead of
-// 48) and keeps classes where j2_body keeps matrix entries: the row's own entries and omega/diag come from the LDS
-// table (sT, sCF: one IEEE division per class and workgroup instead of two per cell and step), the neighbours'
-// +1 / +nx entries through the plane image of the classes (sC).  With so few registers per cell the step is
-// arranged differently: the plane images are multi-buffered and the WHOLE second sweep of plane k is evaluated
-// in the step that relaxes plane k+1 once, from the image of v1[k] written a step earlier -- a step only reads
-// what earlier steps wrote, so there is one barrier per plane instead of two.
+// 48).  A class names the whole row (seven entries + omega/diagonal, one IEEE division per class and workgroup
+// instead of two per cell and step), so there is nothing to look up about the neighbours:
+//   * waves whose 64 cells of a line all carry the level's most frequent class (`cmain`: the interior stencil,
+//     > 99 % of the rows of a large level) take the entries from kernel arguments (SGPRs): no table access at all;
+//   * other cells read their row with four 16-byte LDS loads from the table.
+// The plane images are double-buffered (x and the once-relaxed iterate: plane mod 2) and the WHOLE second sweep of
+// plane k is evaluated in the step that relaxes plane k+1 once, from the image of v1[k] written a step earlier --
+// a step only reads what earlier steps wrote, so there is one barrier per plane.
+//
+// Tile geometry along x.  All tiles of a level are alike (tiles that run at different speeds fall out of step with
+// their neighbours and the cells they share are then fetched twice; measured +10 % with one narrower column): a
+// tile's 128 cells per line are  [ring | W1 first-sweep cells | ring | idle],  W1 = WI + 2 <= 126, of which the
+// inner WI = ceil(nx / ntx) get their second sweep, so that ntx columns cover the nx grid columns without a nearly
+// empty last one (nx = 1025: 9 x 114 instead of 9 x 126).  The two ring cells are ordinary cells whose first-sweep
+// value nobody uses; idle cells are read at the address of the right ring cell (the same memory request: no traffic).
+//
+// What the compiler must not do to the software pipeline (both were measured, both cost > 20 %):
+//   * plane loads through FLAT pointers -- a pointer rebuilt from integers is flat unless its address space is spelled
+//     out, and flat loads count as LDS operations too (lgkmcnt, out of order): every wait for an LDS read then waits
+//     for every global load in flight;
+//   * taking over the loaded values at the END of the loop body (where phi elimination puts the copies), behind the
+//     next loads: the copies wait for the loads just issued.  Hence unconditional loads (nothing under an `if`) and the
+//     empty asm statements that pin the take-over before the loads.
 template <int NW, int LPW> constexpr size_t j2c_lds_bytes() {
-    constexpr int EY = NW * LPW, PV = J2_EX + 2;
-    constexpr size_t v0 = (size_t)(EY + 2) * PV, v1 = (size_t)EY * J2_EX;
-    return sizeof(double) * (256 * 4 + 256 + 2 * v0 + 2 * v1) + 3 * v0;
+    constexpr int EY = NW * LPW;
+    return sizeof(double) * (256 * CLS_W + 2 * (size_t)(EY + 2) * J2_EX + 2 * (size_t)EY * J2_EX + 2 * (J2_EX + 2));
 }
+
+typedef const __attribute__((address_space(1))) char* gcptr_t;
 
 template <int NW, int LPW>
 __device__ __forceinline__ void j2c_body(const J2Args& a) {
-    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW, PV = EX + 2;
+    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW;
     extern __shared__ double j2_smem[];
-    double* const sT = j2_smem;                           // 256 x 4    entries of the row classes
-    double* const sCF = sT + 256 * 4;                     // 256        omega / diagonal
-    // ONE barrier per plane: the images are multi-buffered (slot = plane mod 2 / mod 3), so that a step only reads
-    // what earlier steps wrote and only writes what no wave can still be reading
-    constexpr int V0S = (EY + 2) * PV, V1S = EY * EX, CS = (EY + 2) * PV;
-    double* const sV0 = sCF + 256;                        // 2 x (EY+2) x PV   x of a plane, origin (-1,-1)
+    constexpr int V0S = (EY + 2) * EX, V1S = EY * EX;
+    double* const sT = j2_smem;                           // 256 x 8   entries of the row classes, [7] = omega / diagonal
+    double* const sV0 = sT + 256 * CLS_W + (EX + 2);      // 2 x (EY+2) x EX   x of a plane, origin (0,-1)
     double* const sV1 = sV0 + 2 * V0S;                    // 2 x EY x EX       once-relaxed iterate of a plane
-    unsigned char* const sC = reinterpret_cast<unsigned char*>(sV1 + 2 * V1S);   // 3 x (EY+2) x PV classes, like sV0
-    auto slot3 = [](int plane) -> int { return ((plane % 3) + 3) % 3; };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (cell 0 of the first line reads one element in front of an image, cells of the last line one line behind it:
+    //  EX + 2 elements of slack on both ends of the pair of arrays; such cells store nothing)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: branches on it are s_cbranch
 
     unsigned id;
     {
-        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-        id = ((j >> 5) * 8u + xcd) * 32u + (j & 31u);
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3, ch = a.xcd_chunk;
+        id = ((j / ch) * 8u + xcd) * ch + (j % ch);
     }
     if (id >= a.nitems) return;
     const unsigned ntile = (unsigned)(a.ntx * a.nty);
@@ -438,217 +490,236 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
     else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
     if (z1 <= z0) return;
-    const int tx0 = tix * (EX - 2) - 1, ty0 = tiy * (EY - 2) - 1;
+    const int wi = a.wi, w1 = wi + 2;                     // cells with a second / a first sweep per line
+    const int tx0 = tix * wi - 2, ty0 = tiy * (EY - 2) - 1;           // grid position of cell (0, 0)
 
-    for (int i = threadIdx.x; i < 256 * 4; i += NW * WAVE) sT[i] = a.ctab[i];
-    for (int i = threadIdx.x; i < 256; i += NW * WAVE) {
-        const double d = a.ctab[4 * i];
-        sCF[i] = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+    {
+        const int nt = a.ncls * CLS_W;
+        for (int i = threadIdx.x; i < nt; i += NW * WAVE) {
+            double v = a.ctab[i];
+            if ((i & (CLS_W - 1)) == CLS_W - 1) {
+                const double d = a.ctab[i - 4];
+                v = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+            }
+            sT[i] = v;
+        }
     }
+    // the most frequent class: entries straight from the kernel arguments
+    const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
+    const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    const int cmain = a.cmain;
 
+    // cell c = 2*l + r of this thread: ex = lane + 64 r, ey = wave*LPW + l
     const int ey0 = wave * LPW;
-    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
-    const int lv0 = (ey0 + 1) * PV + lane + 1;
-    const int lw0 = ey0 * EX + lane;
-    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
-    auto lvof = [&](int c) -> int { return lv0 + (c >> 1) * PV + 64 * (c & 1); };
+    const int lw0 = ey0 * EX + lane;                      // cell 0 in sV1; in sV0 it is lw0 + EX
     auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
-    unsigned inT = 0;
+    unsigned inT = 0;           // bit c: this lane's cell c is an interior cell whose second sweep this tile stores
+    unsigned lineT = 0;         // bit c (wave-uniform): the 64 cells c of this wave hold interior cells at all
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
-        if (ex >= 1 && ex < EX - 1 && ey >= 1 && ey < EY - 1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
+        const bool line = ey >= 1 && ey < EY - 1 && ty0 + ey < a.ny && 64 * (c & 1) < w1;
+        if (line) lineT |= 1u << c;
+        if (line && ex >= 2 && ex < w1 && tx0 + ex < a.nx) inT |= 1u << c;
     }
-    const bool hl = lane == 0;
     const bool wlo = wave == 0, whi = wave == NW - 1;
 
-    // Addresses.  Every load of a plane is `uniform base of the plane + a 32-bit element offset fixed for the whole
-    // march`: no per-lane predicates, no 64-bit address arithmetic in the loop.  That needs every address to be
-    // readable whether or not its row exists: the vectors carry zero slack of a plane + 2 lines on both sides
-    // (vec_reach), the class array is padded alike with class 0 (the all-zero row), planes -1 and nz are read like
-    // any other and planes beyond them are skipped by a uniform test.  Grid lines from ny+2 on (tiles that stick
-    // out of the grid; their cells feed no result) are read at line ny+1 so that the slack suffices.
+    // Addresses.  Every load of a plane is `uniform base of the plane + an element offset fixed for the whole march`:
+    // no per-lane predicates, no address arithmetic in the loop.  That needs every address to be readable whether or
+    // not its row exists: the vectors carry zero slack of a plane + 2 lines on both sides (vec_reach), the class array
+    // is padded alike with class 0 (the all-zero row), planes -1 and nz are read like any other and planes beyond
+    // them are read at the nearest of these.  Grid lines from ny+2 on (tiles that stick out of the grid; their cells
+    // feed no result) are read at line ny+1 so that the slack suffices.  x, f and the class of a cell share one offset.
     const unsigned bias = 2u * (unsigned)a.nx + 2u;
-    unsigned eo[LPW], eor;                                   // cell (line l, r = 0); the line of the y ring
+    unsigned eo[NC], eor[2];                                 // the cells; the cells of the y ring's line
 #pragma unroll
-    for (int l = 0; l < LPW; ++l)
-        eo[l] = (unsigned)((int64_t)min(ty0 + ey0 + l, a.ny + 1) * a.nx + tx0 + lane + (int64_t)bias);
-    eor = (unsigned)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + lane + (int64_t)bias);
+    for (int c = 0; c < NC; ++c)
+        eo[c] = (unsigned)((int64_t)min(ty0 + ey0 + (c >> 1), a.ny + 1) * a.nx + tx0 + min(lane + 64 * (c & 1), w1 + 1) + (int64_t)bias);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        eor[r] = (unsigned)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + min(lane + 64 * r, w1 + 1) + (int64_t)bias);
     const unsigned char* const clsb = a.cls + a.clead - bias;       // + plane*P: class of element offset 0
     const double* const xb0 = a.x - bias;
     const double* const fb0 = a.f - bias;
-    // the plane bases are made opaque scalars (readfirstlane) so that the compiler keeps them in SGPRs and emits
-    // `global_load v, v_offset, s[base:base+1] offset:imm` instead of carrying a 64-bit VGPR address per stream
-    auto sbase = [](const void* p) -> const char* {
+    // the plane bases are made opaque scalars (readfirstlane) so that they live in SGPRs
+    auto sbase = [](const void* p) -> gcptr_t {
         const unsigned long long u = (unsigned long long)p;
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        return (gcptr_t)(((unsigned long long)hi << 32) | lo);
     };
-    auto ldd = [](const char* b, unsigned e, int d) -> double { return *reinterpret_cast<const double*>(b + (e << 3) + d * 8); };
-    auto ldc = [](const char* b, unsigned e, int d) -> int { return *reinterpret_cast<const unsigned char*>(b + e + d); };
+    auto ldd = [](gcptr_t b, unsigned e) -> double {
+        return *(const __attribute__((address_space(1))) double*)(b + ((unsigned long long)e << 3));
+    };
+    auto ldc = [](gcptr_t b, unsigned e) -> int {
+        return *(const __attribute__((address_space(1))) unsigned char*)(b + (unsigned long long)e);
+    };
 
-    // classes of the cell in planes k-1, k, k+1: one byte each of cpk (k-1 lowest); c2: plane k+2, in flight
-    unsigned cpk[NC];
-    int c1[NC], c2[NC];
-    auto cls_m = [&](int c) -> int { return (int)(cpk[c] & 255u); };
-    auto cls_0 = [&](int c) -> int { return (int)((cpk[c] >> 8) & 255u); };
-    auto cls_1 = [&](int c) -> int { return (int)((cpk[c] >> 16) & 255u); };
-    double f0[NC], f1[NC], f2[NC], wm[NC], w0[NC], w1[NC], va[NC], vb[NC], vc[NC], vd[NC];
-    double hxl[LPW], hyv[2];
-    int hxc[LPW], hyc[2];
+    // registers per cell: x of planes k, k+1, k+2 (va vb vc) and k+3 (vd, in flight); f and the class of planes k, k+1
+    // and k+2 (in flight, with the y ring of x in plane k+2); the once-relaxed iterate of planes k-1, k, k+1 (wm w0 w1)
+    int c0[NC], c1[NC], c2[NC];
+    double f0[NC], f1[NC], f2[NC], wm[NC], w0[NC], wn[NC], va[NC], vb[NC], vc[NC], vd[NC];
+    double hy[2];
+    unsigned fast = 0;          // wave-uniform; bit c: all 64 cells c of plane k are of class cmain; bit NC + c: plane k+1
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { f0[c] = wm[c] = w0[c] = w1[c] = 0.0; }
-#pragma unroll
-    for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
-    hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
+    for (int c = 0; c < NC; ++c) {
+        f0[c] = f1[c] = f2[c] = wm[c] = w0[c] = wn[c] = va[c] = vb[c] = vc[c] = vd[c] = 0.0;
+        c0[c] = c1[c] = c2[c] = 0;
+    }
+    hy[0] = hy[1] = 0.0;
 
-    auto load_plane = [&](const int plane, const bool on, int (&cc)[NC], double (&fr)[NC]) {
-        if (on && plane >= -1 && plane <= a.nz) {
-            const int64_t o = (int64_t)plane * a.P;
-            const char* const cb = sbase(clsb + o);
-            const char* const fb = sbase(fb0 + o);
-            const char* const xb = sbase(xb0 + o);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
-                fr[c] = ldd(fb, eo[c >> 1], 64 * (c & 1));
-            }
-            if (hl || lane == 63) {                 // x ring: the cell left of ex = 0 / right of ex = EX-1
-#pragma unroll
-                for (int l = 0; l < LPW; ++l) {
-                    hxl[l] = ldd(xb, hl ? eo[l] - 1u : eo[l] + 65u, 0);
-                    hxc[l] = ldc(cb, eo[l], -1);
-                }
-            }
-            if (wlo || whi) {                       // y ring: the line below ey = 0 / above ey = EY-1
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    hyv[r] = ldd(xb, eor, 64 * r);
-                    hyc[r] = ldc(cb, eor, 64 * r);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { cc[c] = 0; fr[c] = 0.0; }
-#pragma unroll
-            for (int l = 0; l < LPW; ++l) { hxl[l] = 0.0; hxc[l] = 0; }
-            hyv[0] = hyv[1] = 0.0; hyc[0] = hyc[1] = 0;
-        }
-    };
-    auto load_x = [&](const int plane, const bool on, double (&v)[NC]) {
-        if (on && plane >= -1 && plane <= a.nz) {
-            const char* const xb = sbase(xb0 + (int64_t)plane * a.P);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = ldd(xb, eo[c >> 1], 64 * (c & 1));
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = 0.0;
-        }
-    };
-    auto load_c = [&](const int plane, int (&cc)[NC]) {
-        if (plane >= -1 && plane <= a.nz) {
-            const char* const cb = sbase(clsb + (int64_t)plane * a.P);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cc[c] = ldc(cb, eo[c >> 1], 64 * (c & 1));
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cc[c] = 0;
-        }
-    };
-    auto park = [&](const int plane, const double (&v)[NC], const int (&cc)[NC]) {
-        unsigned char* const cs = sC + slot3(plane) * CS;
-        double* const xs = sV0 + (plane & 1) * V0S;
+    // Loads never branch (a load under a condition makes the compiler carry its result through copies, and a copy
+    // waits for the load): a plane outside [-1, nz] -- beyond the zero slack -- is read at the nearest plane inside;
+    // what such a plane contributes only reaches rows outside the level, whose results are discarded.
+    // classes + f of a plane, and the y ring of x in that plane (the line below ey = 0 / above ey = EY-1: only the first
+    // and the last wave's exist; the branch is scalar)
+    auto load_cf = [&](const int plane, int (&cc)[NC], double (&fr)[NC]) {
+        const int64_t o = (int64_t)min(max(plane, -1), a.nz) * a.P;
+        const gcptr_t cb = sbase(clsb + o);
+        const gcptr_t fb = sbase(fb0 + o);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int iv = lvof(c);
-            xs[iv] = v[c];
-            cs[iv] = (unsigned char)cc[c];
+            cc[c] = ldc(cb, eo[c]);
+            fr[c] = ldd(fb, eo[c]);
         }
+        if (wlo || whi) {
+            const gcptr_t xb = sbase(xb0 + o);
 #pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            const int rowv = (ey0 + l + 1) * PV;
-            if (hl) { xs[rowv] = hxl[l]; cs[rowv] = (unsigned char)hxc[l]; }
-            if (lane == 63) xs[rowv + EX + 1] = hxl[l];
-        }
-        if (wlo) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) { xs[lane + 64 * r + 1] = hyv[r]; cs[lane + 64 * r + 1] = (unsigned char)hyc[r]; }
-        } else if (whi) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) xs[(EY + 1) * PV + lane + 64 * r + 1] = hyv[r];
+            for (int r = 0; r < 2; ++r) hy[r] = ldd(xb, eor[r]);
         }
     };
-
-    load_plane(z0 - 1, true, c1, f1);
-    load_x(z0 - 2, true, va);
-    load_x(z0 - 1, true, vb);
-    load_x(z0, true, vc);
-    load_c(z0 - 2, c2);
-    park(z0 - 1, vb, c1);
+    auto load_x = [&](const int plane, double (&v)[NC]) {
+        const gcptr_t xb = sbase(xb0 + (int64_t)min(max(plane, -1), a.nz) * a.P);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) cpk[c] = ((unsigned)c2[c] << 8) | ((unsigned)c1[c] << 16);
+        for (int c = 0; c < NC; ++c) v[c] = ldd(xb, eo[c]);
+    };
+    // LDS image of plane `plane` of x (cells + y ring)
+    auto park = [&](const int plane, const double (&v)[NC]) {
+        double* const xs = sV0 + (plane & 1) * V0S;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xs[lwof(c) + EX] = v[c];
+        if (wlo || whi) {
+            const int rowv = wlo ? 0 : (EY + 1) * EX;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) xs[rowv + lane + 64 * r] = hy[r];
+        }
+    };
+    auto all_main = [&](const int (&cc)[NC]) -> unsigned {
+        unsigned m = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(cc[c] != cmain) == 0ull))) m |= 1u << c;
+        return m;
+    };
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
+
+    // ---- warm-up: what step k = z0-2 finds in place ----
+    load_x(z0 - 2, va);
+    load_x(z0 - 1, vb);
+    load_x(z0, vc);
+    load_cf(z0 - 2, c0, f0);
+    load_cf(z0 - 1, c1, f1);                // (with the y ring of plane z0-1)
+    park(z0 - 1, vb);
+    fast = all_main(c0) | (all_main(c1) << NC);
     // the loads of a step are issued BEFORE the barrier that ends the step before it: the time the waves spend at
     // the barrier is flight time too
-    load_plane(z0, z0 <= z1, c2, f2);
-    load_x(z0 + 1, z0 + 1 <= z1 + 1, vd);
+    load_cf(z0, c2, f2);
+    load_x(z0 + 1, vd);
     __syncthreads();
 
     for (int k = z0 - 2; k < z1; ++k) {
-
-        const unsigned char* const cp1 = sC + slot3(k + 1) * CS;      // classes of plane k+1
-        const unsigned char* const cp0 = sC + slot3(k) * CS;          // classes of plane k
-        const double* const x1 = sV0 + ((k + 1) & 1) * V0S;           // x of plane k+1
+        const double* const x1 = sV0 + ((k + 1) & 1) * V0S + EX;      // x of plane k+1, indexed like sV1
         double* const v1w = sV1 + ((k + 1) & 1) * V1S;                // v1 of plane k+1 (written here)
         const double* const v1r = sV1 + (k & 1) * V1S;                // v1 of plane k (written a step ago)
         const int64_t o1 = (int64_t)(k + 1) * a.P;
+        const bool second = k >= z0;
+        const bool keep1 = a.v1out != nullptr && k + 1 >= z0 && k + 1 < z1;
+        // ---- first sweep on plane k+1 ----
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int iv = lvof(c), iw = lwof(c);
-            const double s0 = sT[4 * cls_0(c) + 3];
-            const double* const t1 = sT + 4 * cls_1(c);
-            // first sweep on plane k+1
-            double acc = 0.0;
-            acc = fma(s0, va[c], acc);                                          // -P
-            acc = fma(sT[4 * cp1[iv - PV] + 2], x1[iv - PV], acc);              // -nx
-            acc = fma(sT[4 * cp1[iv - 1] + 1], x1[iv - 1], acc);                // -1
-            acc = fma(t1[0], vb[c], acc);
-            acc = fma(t1[1], x1[iv + 1], acc);                                  // +1
-            acc = fma(t1[2], x1[iv + PV], acc);                                 // +nx
-            acc = fma(t1[3], vc[c], acc);                                       // +P
-            const double o = vb[c] + sCF[cls_1(c)] * (f1[c] - acc);
+            const int iw = lwof(c);
+            const double xs = x1[iw - EX], xw = x1[iw - 1], xe = x1[iw + 1], xn = x1[iw + EX];
+            double o;
+            if (fast >> (NC + c) & 1u) {
+                double acc = 0.0;
+                acc = fma(m0, va[c], acc);                           // -P
+                acc = fma(m1, xs, acc);                              // -nx
+                acc = fma(m2, xw, acc);                              // -1
+                acc = fma(m3, vb[c], acc);
+                acc = fma(m4, xe, acc);                              // +1
+                acc = fma(m5, xn, acc);                              // +nx
+                acc = fma(m6, vc[c], acc);                           // +P
+                o = vb[c] + mcf * (f1[c] - acc);
+            } else {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c1[c]);
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                double acc = 0.0;
+                acc = fma(t01.x, va[c], acc);
+                acc = fma(t01.y, xs, acc);
+                acc = fma(t23.x, xw, acc);
+                acc = fma(t23.y, vb[c], acc);
+                acc = fma(t45.x, xe, acc);
+                acc = fma(t45.y, xn, acc);
+                acc = fma(t67.x, vc[c], acc);
+                o = vb[c] + t67.y * (f1[c] - acc);
+            }
             const int64_t r1 = rowof(c) + o1;
-            w1[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
-            v1w[iw] = w1[c];
-            if (inT >> c & 1u) {
-                const int64_t r0 = r1 - a.P;
-                if (k >= z0 && r0 >= a.st_lo && r0 < a.st_hi) {
-                    // second sweep on plane k: its in-plane neighbours were written a step ago
-                    const double* const t0 = sT + 4 * cls_0(c);
-                    double ac2 = 0.0;
-                    ac2 = fma(sT[4 * cls_m(c) + 3], wm[c], ac2);                // -P
-                    ac2 = fma(sT[4 * cp0[iv - PV] + 2], v1r[iw - EX], ac2);     // -nx
-                    ac2 = fma(sT[4 * cp0[iv - 1] + 1], v1r[iw - 1], ac2);       // -1
-                    ac2 = fma(t0[0], w0[c], ac2);
-                    ac2 = fma(t0[1], v1r[iw + 1], ac2);                         // +1
-                    ac2 = fma(t0[2], v1r[iw + EX], ac2);                        // +nx
-                    ac2 = fma(s0, w1[c], ac2);                                  // +P
-                    a.out[r0] = w0[c] + sCF[cls_0(c)] * (f0[c] - ac2);
+            wn[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
+            v1w[iw] = wn[c];
+            if (keep1 && (inT >> c & 1u) && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = wn[c];
+        }
+        // ---- second sweep on plane k: its in-plane neighbours were written a step ago ----
+        if (second) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!(lineT >> c & 1u)) continue;
+                const int iw = lwof(c);
+                const double ys = v1r[iw - EX], yw = v1r[iw - 1], ye = v1r[iw + 1], yn = v1r[iw + EX];
+                double o;
+                if (fast >> c & 1u) {
+                    double acc = 0.0;
+                    acc = fma(m0, wm[c], acc);
+                    acc = fma(m1, ys, acc);
+                    acc = fma(m2, yw, acc);
+                    acc = fma(m3, w0[c], acc);
+                    acc = fma(m4, ye, acc);
+                    acc = fma(m5, yn, acc);
+                    acc = fma(m6, wn[c], acc);
+                    o = w0[c] + mcf * (f0[c] - acc);
+                } else {
+                    const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c0[c]);
+                    const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                    double acc = 0.0;
+                    acc = fma(t01.x, wm[c], acc);
+                    acc = fma(t01.y, ys, acc);
+                    acc = fma(t23.x, yw, acc);
+                    acc = fma(t23.y, w0[c], acc);
+                    acc = fma(t45.x, ye, acc);
+                    acc = fma(t45.y, yn, acc);
+                    acc = fma(t67.x, wn[c], acc);
+                    o = w0[c] + t67.y * (f0[c] - acc);
                 }
-                if (a.v1out && k + 1 >= z0 && k + 1 < z1 && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = w1[c];
+                const int64_t r0 = rowof(c) + o1 - a.P;
+                if ((inT >> c & 1u) && r0 >= a.st_lo && r0 < a.st_hi) a.out[r0] = o;
             }
         }
-        park(k + 2, vc, c2);
+        // ---- park plane k+2, rotate, issue the loads of the step after the next ----
+        park(k + 2, vc);
+        fast = (fast >> NC) | (all_main(c2) << NC);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            cpk[c] = (cpk[c] >> 8) | ((unsigned)c2[c] << 16);
-            f0[c] = f1[c]; f1[c] = f2[c]; wm[c] = w0[c]; w0[c] = w1[c];
+            c0[c] = c1[c]; c1[c] = c2[c];
+            f0[c] = f1[c]; f1[c] = f2[c]; wm[c] = w0[c]; w0[c] = wn[c];
             va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+            // The values that arrived (classes, f, x of the planes ahead) are taken over HERE, before the registers they
+            // arrived in are handed to the next loads (see the comment above the kernel).
+            asm volatile("" : "+v"(c1[c]));
+            asm volatile("" : "+v"(f1[c]));
+            asm volatile("" : "+v"(vc[c]));
         }
-        if (k + 1 < z1) {
-            load_plane(k + 3, k + 3 <= z1, c2, f2);
-            load_x(k + 4, k + 4 <= z1 + 1, vd);
-        }
+        load_cf(k + 3, c2, f2);
+        load_x(k + 4, vd);
         __syncthreads();
     }
 }

@@ -139,9 +139,13 @@ struct EllArgs {
     unsigned strip_bmax;    // blocks (4 slices each) in the widest strip
     unsigned ps4;           // blocks per pseudo-plane
     unsigned kp;            // pseudo-planes
-    // row classes (sdia_cls_apply): class of row r = cls[r] (row-based, zero-padded), entries in ctab[class][4]
+    // row classes (sdia_cls_apply): class of row r = cls[r] (row-based, zero-padded), the row's seven entries in
+    // ctab[class][CLS_W]; ncls classes in use; cmain = the most frequent one, entries by value in cm[]
     const unsigned char* cls;
     const double* ctab;
+    int ncls, cmain;
+    double cm[8];
+    unsigned nvirt;         // groups of four slices to process (persistent blocks stride over them)
 };
 
 // ---- XCD strip traversal ----------------------------------------------------------------------
@@ -408,58 +412,94 @@ __global__ __launch_bounds__(BLOCK) void sdia_jacobi_finest(EllArgs a) {
 }
 
 // ---- symmetric diagonal storage read through row classes ------------------------------------------
-// Where a level has row classes (mg_jacobi2.hip.h: at most 255 distinct stored rows, bit for bit), the one-sweep
-// kernels need not stream the 32-byte rows either: one class byte per row, the entries from a 256 x 4 table that
-// every block copies into LDS (8 KB, an L2 hit).  Same entries, same order, same results as sdia_body; per row and
+// Where a level has row classes (mg_jacobi2.hip.h: at most 255 distinct FULL rows, bit for bit), the one-sweep
+// kernels need not stream the 32-byte rows either: one class byte per row names the row's seven entries
+// (ctab[class][CLS_W], ascending column order).  Same entries, same order, same results as sdia_body; per row and
 // sweep 1 (class) + 8 (x) + 8 (f) + 8 (out) = 25 B instead of 56 B.  All four modes (residual, Jacobi, SpMV[+dot],
-// Gauss-Seidel colour); seven-point rows only (WU = 4: classes exist for nothing else).
-template <int R, int MODE, bool DOT, bool NT>
+// Gauss-Seidel colour); WU = 4 seven-point rows {0, +-1, +-nx, +-P}, WU = 3 the five-point rows of 2-D levels.
+//   * blocks are persistent (grid-stride over groups of four slices), so the table -- only the classes in use,
+//     64 B each -- is copied into LDS once per block, behind the first group's global loads;
+//   * a wave whose 64*R rows all carry the level's most frequent class (the interior stencil) takes the entries
+//     from the kernel arguments (scalar registers) and touches no table at all.
+constexpr int CLS_W = 8;
+
+template <int WU, int R, int MODE, bool DOT, bool NT>
 __device__ __forceinline__ void sdia_cls_body(const EllArgs& a) {
-    __shared__ double sT[256 * 4];
+    __shared__ double sT[256 * CLS_W];
+    static_assert(WU == 3 || WU == 4, "row classes: five- and seven-point rows");
     if (a.done_flag && *a.done_flag) return;
-    constexpr int S = WAVE * R, WU = 4;
+    constexpr int S = WAVE * R;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    int64_t sl;
-    if (a.strip_ns) {
-        const int64_t first = strip_block(a, blockIdx.x);
-        if (!DOT && first < 0) return;
-        sl = first < 0 ? a.nslices : first + wave;
-    } else {
-        sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
-    }
-    for (int i = threadIdx.x; i < 256 * 4; i += BLOCK) sT[i] = a.ctab[i];
-    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double dot = 0.0;
-    if (sl < a.nslices) {
-        const int64_t slice = a.slice0 + sl;
-        const int64_t row = slice * S + (int64_t)lane * R;
-        const double* xrow = a.x + a.lead + row;
-        const unsigned char* crow = a.cls + row;
-        int own[R], low[WU][R];
-        DVecU<R> xl[WU], xu[WU];
-#pragma unroll
-        for (int r = 0; r < R; ++r) own[r] = crow[r];
-#pragma unroll
-        for (int c = 1; c < WU; ++c) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) low[c][r] = crow[r - a.up[c]];
-            xl[c] = *reinterpret_cast<const DVecU<R>*>(xrow - a.up[c]);
-            xu[c] = *reinterpret_cast<const DVecU<R>*>(xrow + a.up[c]);
+    bool filled = false;
+    for (unsigned vb = blockIdx.x; vb < a.nvirt; vb += gridDim.x) {
+        int64_t sl;
+        if (a.strip_ns) {
+            const int64_t first = strip_block(a, vb);
+            sl = first < 0 ? a.nslices : first + wave;
+        } else {
+            sl = (int64_t)swizzle_block(vb, a.nvirt, a.chunk) * WAVES_PER_BLOCK + wave;
         }
-        const DVec<R> x0 = *reinterpret_cast<const DVec<R>*>(xrow);
+        const bool active = sl < a.nslices;
+        const int64_t row = (a.slice0 + (active ? sl : 0)) * S + (int64_t)lane * R;
+        const double* xrow = a.x + a.lead + row;
+        int own[R];
+        DVecU<R> xl[WU], xu[WU];
+        DVec<R> x0;
+        if (active) {
+            const unsigned char* crow = a.cls + row;
+            if constexpr (R == 1) own[0] = crow[0];
+            else if constexpr (R == 2) {
+                const unsigned w = *reinterpret_cast<const unsigned short*>(crow);
+                own[0] = (int)(w & 255u); own[1] = (int)(w >> 8);
+            } else {
+                const unsigned w = *reinterpret_cast<const unsigned*>(crow);
+#pragma unroll
+                for (int r = 0; r < R; ++r) own[r] = (int)((w >> (8 * r)) & 255u);
+            }
+#pragma unroll
+            for (int c = 1; c < WU; ++c) {
+                xl[c] = *reinterpret_cast<const DVecU<R>*>(xrow - a.up[c]);
+                xu[c] = *reinterpret_cast<const DVecU<R>*>(xrow + a.up[c]);
+            }
+            x0 = *reinterpret_cast<const DVec<R>*>(xrow);
+        }
+        if (!filled) {
+            const int nt = a.ncls * CLS_W;
+            for (int i = threadIdx.x; i < nt; i += BLOCK) sT[i] = a.ctab[i];
+            __syncthreads();
+            filled = true;
+        }
+        if (!active) continue;
+        bool other = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) other = other || own[r] != a.cmain;
+        const bool fast = __builtin_amdgcn_readfirstlane((int)(__ballot(other) == 0ull)) != 0;
         double acc[R], diag[R], xr[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            acc[r] = 0.0;
-#pragma unroll
-            for (int c = WU - 1; c >= 1; --c) acc[r] = fma(sT[4 * low[c][r] + c], xl[c].d[r], acc[r]);
-            const double* const t = sT + 4 * own[r];
+        auto apply = [&](int r, double e0, double e1, double e2, double e3, double e4, double e5, double e6) {
+            double s = 0.0;
+            if constexpr (WU == 4) s = fma(e0, xl[WU - 1].d[r], s);
+            s = fma(e1, xl[2].d[r], s);
+            s = fma(e2, xl[1].d[r], s);
             xr[r] = x0.d[r];
-            diag[r] = t[0] != 0.0 ? t[0] : 1.0;
-            acc[r] = fma(t[0], xr[r], acc[r]);
+            diag[r] = e3 != 0.0 ? e3 : 1.0;
+            s = fma(e3, xr[r], s);
+            s = fma(e4, xu[1].d[r], s);
+            s = fma(e5, xu[2].d[r], s);
+            if constexpr (WU == 4) s = fma(e6, xu[WU - 1].d[r], s);
+            acc[r] = s;
+        };
+        if (fast) {
 #pragma unroll
-            for (int c = 1; c < WU; ++c) acc[r] = fma(t[c], xu[c].d[r], acc[r]);
+            for (int r = 0; r < R; ++r) apply(r, a.cm[0], a.cm[1], a.cm[2], a.cm[3], a.cm[4], a.cm[5], a.cm[6]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * own[r]);
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                apply(r, t01.x, t01.y, t23.x, t23.y, t45.x, t45.y, t67.x);
+            }
         }
         tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
     }
@@ -469,15 +509,15 @@ __device__ __forceinline__ void sdia_cls_body(const EllArgs& a) {
     }
 }
 
-template <int R, int MODE, bool DOT, bool NT>
+template <int WU, int R, int MODE, bool DOT, bool NT>
 __global__ __launch_bounds__(BLOCK) void sdia_cls_apply(EllArgs a) {
-    sdia_cls_body<R, MODE, DOT, NT>(a);
+    sdia_cls_body<WU, R, MODE, DOT, NT>(a);
 }
 
 // (its own symbol for the finest level's Jacobi sweep, like sdia_jacobi_finest)
-template <int R, bool NT>
+template <int WU, int R, bool NT>
 __global__ __launch_bounds__(BLOCK) void sdia_cls_jacobi_finest(EllArgs a) {
-    sdia_cls_body<R, MODE_JACOBI, false, NT>(a);
+    sdia_cls_body<WU, R, MODE_JACOBI, false, NT>(a);
 }
 
 struct SdiaArgs {
@@ -911,7 +951,7 @@ struct FusedRestrictArgs {
     const double* f;        // fine right-hand side, row-based
     double* fc;             // coarse right-hand side, base of storage
     int W, R, coded;        // coded: 0 int32 columns, 1 offset codes, 2 symmetric diagonals (W = WU), 3 the same
-                            // through row classes (cls row-based, ctab[class][4]; seven-point rows)
+                            // through row classes (cls row-based, ctab[class][8]: the full row)
     int up[8];
     int64_t mlead;
     Grid gc, gf;
@@ -938,10 +978,10 @@ __global__ void residual_inject(FusedRestrictArgs a) {
     if (a.coded == 3) {
         const unsigned char* crow = a.cls + row;
         const double* xrow = a.x + a.gf.lead + row;
-        for (int c = 3; c >= 1; --c) acc = fma(a.ctab[4 * crow[-a.up[c]] + c], xrow[-a.up[c]], acc);
-        const double* t = a.ctab + 4 * crow[0];
-        acc = fma(t[0], xrow[0], acc);
-        for (int c = 1; c < 4; ++c) acc = fma(t[c], xrow[a.up[c]], acc);
+        const double* t = a.ctab + 8 * crow[0];             // the whole row: a(-P) a(-nx) a(-1) a(0) a(+1) a(+nx) a(+P)
+        for (int c = a.W - 1; c >= 1; --c) acc = fma(t[3 - c], xrow[-a.up[c]], acc);
+        acc = fma(t[3], xrow[0], acc);
+        for (int c = 1; c < a.W; ++c) acc = fma(t[3 + c], xrow[a.up[c]], acc);
     } else if (a.coded == 2) {
         const int64_t m = row + a.mlead;
         const double* xrow = a.x + a.gf.lead + row;
