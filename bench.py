@@ -38,6 +38,19 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def kernel_source_sha():
+    """Identifies the kernel sources a PMC traffic figure belongs to (profiles/traffic.json)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    base = os.path.join(ROOT, "multigrid_dolfinx_amd", "csrc")
+    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
+        try:
+            hsh.update(open(os.path.join(base, name), "rb").read())
+        except OSError:
+            return None
+    return hsh.hexdigest()[:16]
+
+
 def headline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -303,7 +316,7 @@ def main():
     res_after = h.vcycle(hi, 1, residuals=True)[0]          # untimed: convergence evidence
     f_norm = h.norm2(hi, "f")
 
-    # dominant kernel: one fine-level Jacobi sweep, HIP events on the handle's stream
+    # dominant kernel: the fine-level Jacobi launch, HIP events on the handle's stream
     info = h.level_info(hi)
     jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
     res_ms = h.time_kernel("residual", hi, args.kernel_reps)
@@ -311,35 +324,73 @@ def main():
         pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
     except Exception:
         pair_ms = None
-    pair_plain_ms = None
-    if pair_ms and info.get("row_classes", 0) > 0:
-        # for the record: the same pass reading the 32-byte rows themselves (what a level with more than 255
-        # distinct rows -- variable coefficients -- would run)
-        try:
-            h.set_tuning("fuse_classes", 0)
-            pair_plain_ms = h.time_kernel("jacobi2", hi, max(2, args.kernel_reps // 2))
-        finally:
-            h.set_tuning("fuse_classes", 1 if not any(kv.startswith("fuse_classes=0") for kv in args.tune) else 0)
+    user_tuning = bool(args.tune) or any(v is not None for v in (
+        args.rows_per_lane, args.xcd_chunk, args.offset_codes, args.strip_slices, args.nontemporal,
+        args.symmetric_storage, args.lds_pad))
+    has_classes = info.get("row_classes", 0) > 0
+    classes_in_pair = has_classes and not any(kv.startswith("fuse_classes=0") for kv in args.tune)
+    classes_in_sweep = has_classes and not any(kv.startswith("class_sweeps=0") for kv in args.tune)
     n_loc, z_loc = info["n_local"], info["nnz_nonzero"]
-    # ALGORITHMIC bytes (ELL form): values + int32 columns, read v f D^-1, write v -- what a
-    # plain ELL sweep moves; the shipped formats move less (see roofline.traffic and DESIGN.md section 5)
-    bytes_jacobi = 12 * z_loc + 32 * n_loc
-    bytes_resid = 12 * z_loc + 24 * n_loc
+    W = info["ell_width"]
+
+    def format_bytes_per_row(classes):
+        """Bytes the shipped storage format MUST stream per row and launch: the matrix as stored
+        + read x, read f, write out (+ D^-1 where it is streamed); one pass also when the launch does two sweeps."""
+        if info["symmetric_diagonals"]:
+            return (1 if classes else 8 * info["symmetric_diagonals"]) + 24
+        if info["offset_codes"]:
+            return 8 * W + 8 * ((W + 7) // 8) + 24
+        return 12 * W + 32
+
     sweeps_per_launch = 2 if pair_ms else 1
     dom_ms = pair_ms if pair_ms else jac_ms
-    bytes_launch = sweeps_per_launch * bytes_jacobi
+    dom_classes = classes_in_pair if pair_ms else classes_in_sweep
+    fmt_row = format_bytes_per_row(dom_classes)
+    bytes_launch = fmt_row * n_loc
     achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # SURVEY.md 8(d)'s CSR byte model of the same work, for comparison only (never a roofline fraction: the shipped
+    # formats do not move these bytes)
+    csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
+    if pair_ms:
+        kernel_id = ("sdia_jacobi2c_finest<12, 2>" if dom_classes else "sdia_jacobi2_finest<2, 8, 2, false>")
+    elif info["symmetric_diagonals"]:
+        kernel_id = ("sdia_cls_jacobi_finest<%d, 2, true>" % info["symmetric_diagonals"]) if dom_classes else \
+                    ("sdia_jacobi_finest<%d, 2, true>" % info["symmetric_diagonals"])
+    else:
+        kernel_id = ("ell_apply_coded" if info["offset_codes"] else "ell_apply") + "<..., MODE_JACOBI>"
+    # measured HBM-side traffic of exactly this kernel (PMC passes, profiles/): only quoted when the figure was
+    # taken from the kernel sources that are running now, on this configuration, with default tuning
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    src_sha = kernel_source_sha()
     if os.path.exists(tpath):
         try:
-            t = json.load(open(tpath))
-            key = f"{args.config}_gpus{args.gpus}"
-            classes = bool(pair_ms) and info.get("row_classes", 0) > 0 and not any(kv.startswith("fuse_classes=0") for kv in args.tune)
-            traffic = t.get(key, {}).get(("jacobi2c_hbm_bytes_per_launch" if classes else "jacobi2_hbm_bytes_per_launch")
-                                         if pair_ms else "jacobi_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            entry = json.load(open(tpath)).get("entries", {}).get(f"{args.config}_gpus{args.gpus}:{kernel_id}")
+            if entry is None:
+                traffic_note = "no PMC figure for this kernel / configuration"
+            elif user_tuning:
+                traffic_note = "tuning differs from the profiled run"
+            elif entry.get("kernel_source_sha") != src_sha:
+                traffic_note = f"kernel sources changed since {entry.get('profile')} was taken"
+            else:
+                traffic, traffic_note = entry["hbm_bytes_per_launch"], entry.get("profile")
+        except Exception as exc:           # noqa: BLE001
+            traffic_note = f"profiles/traffic.json unreadable: {exc}"
+
+    # the rate a level WITHOUT row classes gets (more than 255 distinct rows: variable coefficients, row-dependent
+    # round-off in the assembly): the same cycles with the class byte switched off, timed the same way
+    value_plain = pair_plain_ms = None
+    if has_classes and not user_tuning:
+        h.set_tuning("fuse_classes", 0)
+        h.set_tuning("class_sweeps", 0)
+        try:
+            k_plain = max(1, min(args.steps, 5))
+            value_plain = k_plain / timed_cycles(h, rv, hi, 1, k_plain)
+            if pair_ms:
+                pair_plain_ms = h.time_kernel("jacobi2", hi, max(2, args.kernel_reps // 2))
+        finally:
+            h.set_tuning("fuse_classes", 1)
+            h.set_tuning("class_sweeps", 1)
 
     # conventional V(2,2) for information (SURVEY.md §8(d))
     h.set_params(2, 2, args.omega)
@@ -365,26 +416,35 @@ def main():
                        "parallelism": (f"slab{args.gpus}" + ("-gloo-host-staged" if args.transport == "gloo" else ""))
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": (("sdia_jacobi2c<...> (two fine-level weighted-Jacobi sweeps per launch, class-coded rows)"
-                                     if info.get("row_classes", 0) > 0 else
-                                     "sdia_jacobi2<...> (two fine-level weighted-Jacobi sweeps per launch)")) if pair_ms else
-                                   ("sdia_apply" if info["symmetric_diagonals"] else
-                                    "ell_apply_coded" if info["offset_codes"] else "ell_apply")
-                                   + "<..., MODE_JACOBI> (fine-level weighted-Jacobi sweep)",
-                         "sweeps_per_launch": sweeps_per_launch, "single_sweep_kernel_ms": jac_ms,
-                         "kernel_ms_without_row_classes": pair_plain_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": kernel_id + (" (two fine-level weighted-Jacobi sweeps per launch" if pair_ms else
+                                                " (one fine-level weighted-Jacobi sweep per launch") +
+                                   (", class-coded rows)" if dom_classes else ")"),
+                         "bytes_model": (f"{fmt_row} B per row and launch = what the shipped format must stream: "
+                                         + ("1 class byte" if dom_classes else "matrix as stored")
+                                         + " + x 8 + f 8 + out 8" + ("" if info["symmetric_diagonals"] or info["offset_codes"] else " + D^-1 8")
+                                         + "; rows_per_launch x that / kernel_ms"),
+                         "format_bytes_per_row": fmt_row, "sweeps_per_launch": sweeps_per_launch,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
                          "row_classes": info.get("row_classes", 0),
                          "storage": ("symmetric diagonals" if info["symmetric_diagonals"] else
                                      "offset-coded ELL" if info["offset_codes"] else "ELL with int32 columns"),
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "rows_per_launch": n_loc, "nonzeros_per_launch": z_loc, "per_gpu": True,
-                         # what the kernel really moves (PMC, profiles/traffic.json) per second: the shipped
-                         # formats move fewer bytes than the algorithmic count, hence frac can exceed 1
+                         # what crosses the L2/fabric boundary per second (PMC): includes tile rims and re-reads
                          "traffic_GBs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "single_sweep_kernel_ms": jac_ms,
+                         "single_sweep_frac": format_bytes_per_row(classes_in_sweep) * n_loc / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "residual_kernel_ms": res_ms,
-                         "residual_achieved_GBs": bytes_resid / (res_ms * 1e-3) / 1e9},
+                         "residual_frac": (format_bytes_per_row(classes_in_sweep) - 0) * n_loc / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_without_row_classes": pair_plain_ms,
+                         "frac_without_row_classes": (format_bytes_per_row(False) * n_loc / (pair_plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                                     if pair_plain_ms else None,
+                         # SURVEY.md 8(d)'s CSR model of the same sweeps (12 z + 36 n per sweep) over the same time: how much
+                         # faster than a kernel that streams CSR at the same byte rate -- NOT a fraction of the roofline
+                         "csr_model_bytes_per_launch": csr_model_bytes,
+                         "speedup_vs_csr_model": csr_model_bytes / bytes_launch},
+            "value_without_row_classes": value_plain,
             "v22_cycles_per_s": v22_per_s, "residual_l2_after": res_after, "rhs_l2": f_norm,
             "setup_s": t_setup, "device_memory_GB_per_gpu": mem / 1e9, "device": dev,
         }

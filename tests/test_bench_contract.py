@@ -29,6 +29,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the fraction is priced on the bytes the shipped format must stream: it cannot exceed the roofline, and it is
+    # reproducible from the line itself
+    assert 0.0 < r["frac"] <= 1.0
+    assert abs(r["achieved"] - r["format_bytes_per_row"] * r["rows_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.9
+    assert "speedup_vs_csr_model" in r and "value_without_row_classes" in d
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
