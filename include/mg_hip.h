@@ -230,6 +230,22 @@ int mg_quadratic_form(mg_handle h, int level, int which, double* out);
 int mg_set_rhs_true(mg_handle h, int level, const double* host);
 int mg_fmg(mg_handle h, int top_level, int mu0, double tol, int max_cycles, double* resid_l2,
            int* cycles_done);
+/* FullMultiGrid with the reference's own norms, device-resident (multigrid.py:285-302: the stop test `resn <= 1e-11`
+ * and the two histories use res_calculator / err_calculator = sqrt(int r_h^2), sqrt(int (u_h - u_exact)^2),
+ * multigrid.py:203-218).  norm = MG_NORM_MASS evaluates them as sqrt(x^T M x) with the P1 mass matrix M of the
+ * top level handed over by mg_set_mass_csr (same DoF numbering and CSR conventions as mg_set_level_csr; it stands
+ * in for the dolfinx function space `V_fine_dolfx`); MG_NORM_L2 is the Euclidean norm.  err_hist (optional)
+ * needs the exact solution's nodal values (mg_set_exact = `u_exact_fine`).  Per cycle only two doubles cross to
+ * the host.  resid_hist / err_hist hold max(mu0, max_cycles) entries. */
+enum { MG_NORM_L2 = 0, MG_NORM_MASS = 1 };
+int mg_set_mass_csr(mg_handle h, int level, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                    const int32_t* indices, const double* data);
+int mg_set_exact(mg_handle h, int level, const double* host);
+int mg_fmg_ex(mg_handle h, int top_level, int mu0, double tol, int max_cycles, int norm, double* resid_hist,
+              double* err_hist, int* cycles_done);
+/* Bookkeeping for tests: whole-vector host -> device / device -> host copies made through this handle so far,
+ * V-cycles replayed from a captured hipGraph, graphs currently cached.  No reference counterpart. */
+int mg_counters(mg_handle h, int64_t* uploads, int64_t* downloads, int64_t* graph_replays, int* graphs_cached);
 
 /* ---- measurement -----------------------------------------------------------------------------
  * mg_time_kernel: average duration in milliseconds of `reps` back-to-back launches of

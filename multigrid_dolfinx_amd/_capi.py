@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 MG_VEC_V, MG_VEC_F, MG_VEC_R, MG_VEC_ERR = 0, 1, 2, 3
 MG_RESTRICT_INJECTION, MG_RESTRICT_FULL_WEIGHTING = 0, 1
 MG_SMOOTH_JACOBI, MG_SMOOTH_RBGS = 0, 1
+MG_NORM_L2, MG_NORM_MASS = 0, 1
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
@@ -63,6 +64,10 @@ SIGNATURES = {
     "mg_quadratic_form": [_H, C.c_int, C.c_int, _dp],
     "mg_set_rhs_true": [_H, C.c_int, C.c_void_p],
     "mg_fmg": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, _ip],
+    "mg_set_mass_csr": [_H, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "mg_set_exact": [_H, C.c_int, C.c_void_p],
+    "mg_fmg_ex": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _ip],
+    "mg_counters": [_H, _i64p, _i64p, _i64p, _ip],
     "mg_time_kernel": [_H, C.c_char_p, C.c_int, C.c_int, _dp],
     "mg_sync": [_H],
     "mg_memory_bytes": [_H, _i64p],

@@ -197,6 +197,11 @@ struct mg_context {
     int use_sdia = 1;           // symmetric diagonal storage where a level is bit-for-bit symmetric
     int strip_slices = 64;      // XCD strip traversal for 3-D levels (0 = chunked map only)
     int nontemporal = 1;        // streaming loads for matrix / rhs data
+    // Dynamic LDS bytes requested per block by the symmetric-diagonal launches on large levels.  The kernels do not
+    // use it; it caps the resident blocks per CU at 160 KiB / pad = 5 (20 waves instead of the 28 the register
+    // budget allows), which measured 2.4 % faster on the 1025^3 sweep in an interleaved A/B (tools/ab_lds_pad.py:
+    // 11.64 vs 11.93 ms; 3 blocks per CU: 14.2 ms) -- fewer concurrent streams per HBM page.
+    int lds_pad = 32768;
     int rows_per_lane = 2;      // measured best on MI355X (profiles/): 16 B value loads per lane
     unsigned chunk = 8;         // XCD chunk of the block -> tile map
     int pcg_chunk = 16;
@@ -229,6 +234,13 @@ struct mg_context {
     int fuse_xcd_chunk = 32;        // consecutive tiles of that pass per XCD at a time
     int cls_blocks_per_cu = 4;      // persistent blocks of the one-sweep class kernels (72 VGPRs, 94 SGPRs admit 7)
     DirectSolver direct;
+    // the reference's L2(Omega) norms (res_calculator / err_calculator, multigrid.py:203-218) on the device: a mass
+    // matrix M of one level (mg_set_mass_csr), optionally the exact solution's nodal values (mg_set_exact)
+    Level mass;
+    int mass_level = -1;
+    DVector mass_out, diff, uexact;
+    int uexact_level = -1;
+    int64_t uploads = 0, downloads = 0, graph_replays = 0;   // whole-vector host <-> device copies; hipGraphLaunch calls
     double* stage = nullptr;        // device staging for host vectors (caller numbering)
     int64_t stage_elems = 0;
     int64_t bytes = 0;
@@ -319,8 +331,7 @@ int need_grid(mg_context* c, int level) {
 // ---- slab geometry ---------------------------------------------------------------------------
 // Plane boundaries on the coarsest grid t_g = floor(g*N0/G) (t_G = N0+1); level l uses
 // t_g * 2^l, so coarse plane K and fine plane 2K always live on the same rank.
-int setup_geometry(mg_context* c, int level, int N, int64_t flat_rows = 0) {
-    Level& L = c->L[level];
+int setup_geometry(mg_context* c, Level& L, int level, int N, int64_t flat_rows = 0) {
     const int dim = c->dim;
     const Comm& cm = c->comm;
     Grid& g = L.g;
@@ -387,7 +398,6 @@ void free_level(mg_context* c, Level& L) {
     ++c->epoch;
     drop_graphs(c);
     if (&L == &c->L[0]) free_direct(c);
-    if (!L.set && !L.vals) return;
     const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
     dev_free(c, L.vals, ell);
     dev_free(c, L.cols, ell);
@@ -447,15 +457,9 @@ void launch_ell_coded_wr(int mode, bool dot, bool nt, const EllArgs& a, unsigned
     else launch_ell_coded_wrn<WT, R, false>(mode, dot, a, grid, s);
 }
 
-// Dynamic LDS bytes requested per block by the symmetric-diagonal launches on large levels.  The kernels do
-// not use it; it caps the resident blocks per CU at 160 KiB / pad = 5 (20 waves instead of the 28 the
-// register budget allows), which measured 2.4 % faster on the 1025^3 sweep in an interleaved A/B
-// (tools/ab_lds_pad.py: 11.64 vs 11.93 ms; 3 blocks per CU: 14.2 ms) -- fewer concurrent streams per HBM page.
-int g_lds_pad = 32768;
-
 template <int WU, int R, bool NT>
-void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
-    const unsigned lds = a.nslices >= 100000 ? (unsigned)g_lds_pad : 0u;
+void launch_sdia_wrn(int mode, bool dot, bool finest, const EllArgs& a, unsigned grid, hipStream_t s, int lds_pad) {
+    const unsigned lds = a.nslices >= 100000 ? (unsigned)lds_pad : 0u;
     if (mode == MODE_JACOBI && finest)
         hipLaunchKernelGGL((sdia_jacobi_finest<WU, R, NT>), dim3(grid), dim3(BLOCK), lds, s, a);
     else if (mode == MODE_RESIDUAL)
@@ -498,11 +502,11 @@ void launch_sdia_cls_r(int WU, int mode, bool dot, bool nt, bool finest, const E
 }
 
 template <int R>
-void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s) {
+void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllArgs& a, unsigned grid, hipStream_t s, int pad) {
     switch (WU) {
-        case 3: nt ? launch_sdia_wrn<3, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<3, R, false>(mode, dot, finest, a, grid, s); break;
-        case 4: nt ? launch_sdia_wrn<4, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<4, R, false>(mode, dot, finest, a, grid, s); break;
-        default: nt ? launch_sdia_wrn<8, R, true>(mode, dot, finest, a, grid, s) : launch_sdia_wrn<8, R, false>(mode, dot, finest, a, grid, s); break;
+        case 3: nt ? launch_sdia_wrn<3, R, true>(mode, dot, finest, a, grid, s, pad) : launch_sdia_wrn<3, R, false>(mode, dot, finest, a, grid, s, pad); break;
+        case 4: nt ? launch_sdia_wrn<4, R, true>(mode, dot, finest, a, grid, s, pad) : launch_sdia_wrn<4, R, false>(mode, dot, finest, a, grid, s, pad); break;
+        default: nt ? launch_sdia_wrn<8, R, true>(mode, dot, finest, a, grid, s, pad) : launch_sdia_wrn<8, R, false>(mode, dot, finest, a, grid, s, pad); break;
     }
 }
 
@@ -588,9 +592,9 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
             return 0;
         }
         switch (L.R) {
-            case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
-            case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
-            case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, finest, a, grid, c->stream); break;
+            case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
+            case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
+            case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
             default: return fail("unsupported rows_per_lane");
         }
         HIP_TRY(hipGetLastError());
@@ -733,11 +737,20 @@ DVector* pick(Level& L, int which) {
 
 // Two sweeps in one pass (mg_jacobi2.hip.h): whole, undistributed 3-D levels whose stored diagonals are exactly
 // {0, +1, +nx, +plane}.
+// rows of the smallest slab of a level: decisions that every rank must take alike are made on it, not on the rank's
+// own row count (uneven splits differ by 2^level planes)
+int64_t min_slab_rows(const Level& L) {
+    if (L.replicated || L.splits.size() < 2) return L.nloc;
+    int nk = INT32_MAX;
+    for (size_t r = 0; r + 1 < L.splits.size(); ++r) nk = std::min(nk, L.splits[r + 1] - L.splits[r]);
+    return (int64_t)nk * L.g.plane;
+}
+
 bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     if (!c->fuse_sweeps || !L.sdia || L.wu != 4 || L.flat) return false;
-    if (L.g.nx < 32 || L.g.ny < 32 || L.g.nk < 8) return false;    // zero slack >= 3 slices, slabs >= 8 planes
+    if (L.g.nx < 32 || L.g.ny < 32 || min_slab_rows(L) < 8 * L.g.plane) return false;    // zero slack >= 3 slices, slabs >= 8 planes
     if (L.up[1] != 1 || L.up[2] != L.g.nx || (int64_t)L.up[3] != L.g.plane) return false;
-    return ignore_size || L.nloc >= c->fuse_min_rows;
+    return ignore_size || min_slab_rows(L) >= c->fuse_min_rows;
 }
 
 // Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per function (and device: one
@@ -911,8 +924,11 @@ int smooth(mg_context* c, int level, int nw) {
     const int64_t hi_begin = std::max<int64_t>(lo_end, (L.nloc - L.g.plane) / S);
     // below a few million rows a sweep is shorter than the extra launches and event hops of the overlapped
     // form: exchange in-stream there
-    const bool overlap = dist && c->overlap && hi_begin > lo_end && c->comm_stream && L.nloc >= c->overlap_min_rows;
-    const bool fused = fused_sweeps_ok(c, L) && (!dist || hi_begin > lo_end);
+    // (taken alike on every rank: every slab of a distributed level has at least 2^level >= 2 planes)
+    const bool two_planes = min_slab_rows(L) >= 2 * L.g.plane;
+    const bool overlap = dist && c->overlap && two_planes && hi_begin > lo_end && c->comm_stream &&
+                         min_slab_rows(L) >= c->overlap_min_rows;
+    const bool fused = fused_sweeps_ok(c, L) && (!dist || (two_planes && hi_begin > lo_end));
     J2Plan plan{};
     if (fused && nw > 1) {
         if (dist) MG_TRY(vec_alloc(c, L, &L.sw));
@@ -1325,6 +1341,7 @@ int vcycle_graphed(mg_context* c, int level) {
     for (auto& g : c->graphs) {
         if (g.level != level || g.epoch != c->epoch || g.pre != pre) continue;
         HIP_TRY(hipGraphLaunch(g.exec, c->stream));
+        ++c->graph_replays;
         for (int l = 0; l <= level; ++l)
             if (c->L[l].v.raw != g.post[l]) std::swap(c->L[l].v, c->L[l].v2);
         return 0;
@@ -1360,6 +1377,7 @@ int ensure_stage(mg_context* c, int64_t elems) {
 
 int upload_vector(mg_context* c, Level& L, DVector& v, const double* host) {
     MG_TRY(ensure_stage(c, L.n_global));
+    ++c->uploads;
     HIP_TRY(hipMemcpyAsync(c->stage, host, (size_t)L.n_global * 8, hipMemcpyHostToDevice, c->stream));
     const unsigned nb = (unsigned)std::min<int64_t>(4096, (L.n_global + 255) / 256);
     hipLaunchKernelGGL(scatter_in, dim3(nb), dim3(256), 0, c->stream, c->stage, L.perm, L.n_global, L.row0, L.g.lead,
@@ -1646,6 +1664,8 @@ int mg_destroy(mg_handle c) {
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     drop_graphs(c);
     for (auto& L : c->L) free_level(c, L);
+    free_level(c, c->mass);
+    (void)hipFree(c->mass_out.raw); (void)hipFree(c->diff.raw); (void)hipFree(c->uexact.raw);
     (void)hipFree(c->partials);
     (void)hipFree(c->scalars);
     (void)hipFree(c->done);
@@ -1759,10 +1779,16 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
     if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
     if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
     if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS) return fail("unknown smoother");
+    const double rtol = coarse_rtol > 0 ? coarse_rtol : c->coarse_rtol;
+    const int maxit = coarse_maxit > 0 ? coarse_maxit : c->coarse_maxit;
+    // captured V-cycles (vcycle_graphed) are keyed on the epoch: callers such as the Python shim set the same
+    // parameters before every cycle, which must not throw the graphs away
+    if (mu1 == c->mu1 && mu2 == c->mu2 && omega == c->omega && restriction == c->restriction && smoother == c->smoother &&
+        rtol == c->coarse_rtol && maxit == c->coarse_maxit && keep_err == c->keep_err)
+        return 0;
     ++c->epoch;
     c->mu1 = mu1; c->mu2 = mu2; c->omega = omega; c->restriction = restriction; c->smoother = smoother;
-    if (coarse_rtol > 0) c->coarse_rtol = coarse_rtol;
-    if (coarse_maxit > 0) c->coarse_maxit = coarse_maxit;
+    c->coarse_rtol = rtol; c->coarse_maxit = maxit;
     c->keep_err = keep_err;
     return 0;
 }
@@ -1801,7 +1827,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "nontemporal") {
         c->nontemporal = value != 0;
     } else if (k == "lds_pad") {
-        g_lds_pad = (int)value;
+        if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range");
+        c->lds_pad = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0;
     } else if (k == "overlap_min_rows") {
@@ -1881,7 +1908,7 @@ int upload_permutation(mg_context* c, Level& L, const int64_t* grid_index, int64
 
 int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int64_t nnz, const void* indptr,
                          int indptr_is_64, const int32_t* indices, const double* data, const int64_t* grid_index,
-                         int prune_zeros) {
+                         int prune_zeros, bool vectors = true) {
     // upload the hand-off
     DevTemp d_ptr, d_idx, d_val;
     const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
@@ -1928,6 +1955,7 @@ int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int
     MG_TRY(encode_level(c, L));
     MG_TRY(repack_sdia(c, L, level));
     L.has_matrix = true;
+    if (!vectors) { L.set = true; return 0; }
     return finish_level(c, L);
 }
 
@@ -1941,7 +1969,7 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
     HIP_TRY(hipSetDevice(c->device));
     Level& L = c->L[level];
     free_level(c, L);
-    MG_TRY(setup_geometry(c, level, N, n_rows));
+    MG_TRY(setup_geometry(c, L, level, N, n_rows));
     if (n_rows != L.n_global)
         return fail("matrix has " + std::to_string(n_rows) + " rows, grid has " + std::to_string(L.n_global));
     const int rc = build_level_from_csr(c, level, L, n_rows, nnz, indptr, indptr_is_64, indices, data, grid_index,
@@ -1960,7 +1988,7 @@ int mg_set_level_grid(mg_handle c, int level, int N, int64_t n_rows, const int64
     HIP_TRY(hipSetDevice(c->device));
     Level& L = c->L[level];
     free_level(c, L);
-    MG_TRY(setup_geometry(c, level, N, n_rows));
+    MG_TRY(setup_geometry(c, L, level, N, n_rows));
     if (n_rows != L.n_global)
         return fail("vector has " + std::to_string(n_rows) + " entries, grid has " + std::to_string(L.n_global));
     int rc = upload_permutation(c, L, grid_index, n_rows);
@@ -1979,7 +2007,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     HIP_TRY(hipSetDevice(c->device));
     Level& L = c->L[level];
     free_level(c, L);
-    MG_TRY(setup_geometry(c, level, N));
+    MG_TRY(setup_geometry(c, L, level, N));
     GenArgs a{};
     a.g = L.g; a.N = N; a.dim = c->dim; a.prune = prune_zeros;
     a.h = 1.0 / (double)N;
@@ -2107,6 +2135,7 @@ int mg_get_vector(mg_handle c, int level, int which, double* host, int gather) {
     DVector* v = pick(L, which);
     if (!v || !v->raw) return fail("vector is not available on this level");
     MG_TRY(ensure_stage(c, L.n_global));
+    ++c->downloads;
     const unsigned nb = (unsigned)std::min<int64_t>(4096, (L.n_global + 255) / 256);
     if (gather && !L.replicated && c->comm.active()) {
         // all-gather slabs in lexicographic order inside a scratch vector, then permute
@@ -2254,6 +2283,124 @@ int mg_quadratic_form(mg_handle c, int level, int which, double* out) {
     return 0;
 }
 
+namespace {
+
+__global__ void vec_diff(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = a[t] - b[t];
+}
+
+// c->scalars[slot] = x^T M x with the handle's mass matrix (x: a vector of the mass matrix's level, halos valid)
+int mass_form(mg_context* c, Level& L, DVector& x, int slot) {
+    Level& M = c->mass;
+    MG_TRY(vec_alloc(c, L, &c->mass_out));
+    const unsigned nparts = blocks_for(M.nslices, WAVES_PER_BLOCK);
+    if (nparts > 2 * kMaxParts) {
+        // more partial sums than the handle's scratch holds: a buffer of its own for this call
+        double* parts = nullptr;
+        MG_TRY(dev_alloc(c, &parts, nparts));
+        unsigned grid = 0;
+        int rc = launch_ell(c, M, MODE_SPMV, true, x.base, nullptr, c->mass_out.rows, parts, nullptr, &grid);
+        if (!rc) hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(BLOCK), 0, c->stream, parts, (int)grid, c->scalars + slot);
+        if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("mass_form: stream error");
+        dev_free(c, parts, nparts);
+        MG_TRY(rc);
+    } else {
+        unsigned grid = 0;
+        MG_TRY(launch_ell(c, M, MODE_SPMV, true, x.base, nullptr, c->mass_out.rows, c->partials, nullptr, &grid));
+        hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(BLOCK), 0, c->stream, c->partials, (int)grid, c->scalars + slot);
+    }
+    HIP_TRY(hipGetLastError());
+    if (!L.replicated) MG_TRY(allreduce_sum(c, c->scalars + slot, 1));
+    return 0;
+}
+
+// after a cycle on the top level: residual norm (and error norm) of the iterate in the chosen norm, one small
+// device -> host copy for both
+int fmg_norms(mg_context* c, int l, int norm, bool want_err, double* rn, double* en) {
+    Level& L = c->L[l];
+    MG_TRY(residual(c, l));
+    if (norm == MG_NORM_MASS) {
+        MG_TRY(exchange_halo(c, L, L.v2));
+        MG_TRY(mass_form(c, L, L.v2, 0));
+    } else {
+        MG_TRY(dot_device(c, L, L.v2.rows, L.v2.rows, 0));
+    }
+    if (want_err) {
+        MG_TRY(vec_alloc(c, L, &c->diff));
+        const unsigned nb = (unsigned)std::min<int64_t>(4096, (L.nloc + 255) / 256);
+        hipLaunchKernelGGL(vec_diff, dim3(nb), dim3(256), 0, c->stream, L.v.rows, c->uexact.rows, c->diff.rows, L.nloc);
+        HIP_TRY(hipGetLastError());
+        if (norm == MG_NORM_MASS) {
+            MG_TRY(exchange_halo(c, L, c->diff));
+            MG_TRY(mass_form(c, L, c->diff, 1));
+        } else {
+            MG_TRY(dot_device(c, L, c->diff.rows, c->diff.rows, 1));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_scalars, c->scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *rn = std::sqrt(std::max(0.0, c->h_scalars[0]));
+    if (want_err) *en = std::sqrt(std::max(0.0, c->h_scalars[1]));
+    return 0;
+}
+
+}  // namespace
+
+int mg_set_mass_csr(mg_handle c, int level, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
+                    const int32_t* indices, const double* data) {
+    MG_TRY(check_level(c, level));
+    MG_TRY(need_grid(c, level));
+    if (!indptr || !indices || !data) return fail("null CSR arrays");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    if (n_rows != L.n_global) return fail("mass matrix has " + std::to_string(n_rows) + " rows, level has " + std::to_string(L.n_global));
+    Level& M = c->mass;
+    free_level(c, M);
+    c->mass_level = -1;
+    M = Level();
+    MG_TRY(setup_geometry(c, M, level, L.N));
+    int rc = 0;
+    if (L.perm) {                       // the level's DoF numbering
+        rc = dev_alloc(c, &M.perm, (size_t)L.n_global);
+        if (!rc && hipMemcpy(M.perm, L.perm, (size_t)L.n_global * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess)
+            rc = fail("copy of the level's permutation failed");
+    }
+    // (level index 1: any level but the coarsest may use symmetric diagonal storage)
+    if (!rc) rc = build_level_from_csr(c, 1, M, n_rows, nnz, indptr, indptr_is_64, indices, data, nullptr, 1, false);
+    if (rc) {
+        const std::string why = g_err;
+        free_level(c, M);
+        g_err = why;
+        return rc;
+    }
+    c->mass_level = level;
+    return 0;
+}
+
+int mg_set_exact(mg_handle c, int level, const double* host) {
+    MG_TRY(check_level(c, level));
+    if (!host) return fail("null host vector");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    if (c->uexact.raw && c->uexact_level != level) {
+        vec_free(c, c->L[c->uexact_level], &c->uexact);
+        if (c->diff.raw) vec_free(c, c->L[c->uexact_level], &c->diff);
+    }
+    MG_TRY(vec_alloc(c, L, &c->uexact));
+    c->uexact_level = level;
+    return upload_vector(c, L, c->uexact, host);
+}
+
+int mg_counters(mg_handle c, int64_t* uploads, int64_t* downloads, int64_t* graph_replays, int* graphs_cached) {
+    if (!c) return fail("null handle");
+    if (uploads) *uploads = c->uploads;
+    if (downloads) *downloads = c->downloads;
+    if (graph_replays) *graph_replays = c->graph_replays;
+    if (graphs_cached) *graphs_cached = (int)c->graphs.size();
+    return 0;
+}
+
 int mg_vcycle(mg_handle c, int level, int ncycles, double* resid_l2) {
     MG_TRY(check_level(c, level));
     for (int l = 0; l <= level; ++l) {
@@ -2273,12 +2420,16 @@ int mg_vcycle(mg_handle c, int level, int ncycles, double* resid_l2) {
     return 0;
 }
 
-int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* resid_l2, int* cycles_done) {
+int mg_fmg_ex(mg_handle c, int top, int mu0, double tol, int max_cycles, int norm, double* resid_hist, double* err_hist,
+              int* cycles_done) {
     MG_TRY(check_level(c, top));
     for (int l = 0; l <= top; ++l) {
         MG_TRY(need_matrix(c, l));
         if (top > 0) MG_TRY(need_grid(c, l));
     }
+    if (norm != MG_NORM_L2 && norm != MG_NORM_MASS) return fail("unknown norm");
+    if (norm == MG_NORM_MASS && c->mass_level != top) return fail("mg_fmg_ex: no mass matrix on the top level (mg_set_mass_csr)");
+    if (err_hist && (!c->uexact.raw || c->uexact_level != top)) return fail("mg_fmg_ex: no exact solution on the top level (mg_set_exact)");
     HIP_TRY(hipSetDevice(c->device));
     for (int l = 0; l < top; ++l) {
         Level& L = c->L[l];
@@ -2287,6 +2438,7 @@ int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* re
     }
     MG_TRY(coarse_solve(c, nullptr, nullptr));
     int done_cycles = 0;
+    const bool norms = resid_hist != nullptr || err_hist != nullptr;
     for (int l = 1; l <= top; ++l) {
         Level& L = c->L[l];
         if (l < top)   // cycles on level l-1 consumed F[l-1..0]; F[l] is still the true right-hand side
@@ -2296,31 +2448,27 @@ int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* re
         MG_TRY(prolong(c, l, 0));
         HIP_TRY(hipMemcpyAsync(L.v.base, L.err.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
         MG_TRY(exchange_halo(c, L, L.v));
-        if (l < top || tol <= 0.0) {
-            for (int k = 0; k < mu0; ++k) {
-                MG_TRY(vcycle_graphed(c, l));
-                if (l == top) {
-                    ++done_cycles;
-                    if (resid_l2) {
-                        MG_TRY(residual(c, l));
-                        MG_TRY(norm2(c, L, L.v2.rows, &resid_l2[k]));
-                    }
-                }
-            }
-        } else {
-            for (int k = 0; k < max_cycles; ++k) {
-                MG_TRY(vcycle_graphed(c, l));
-                ++done_cycles;
-                MG_TRY(residual(c, l));
-                double rn = 0.0;
-                MG_TRY(norm2(c, L, L.v2.rows, &rn));
-                if (resid_l2) resid_l2[k] = rn;
-                if (rn <= tol) break;
-            }
+        const bool until_tol = l == top && tol > 0.0;
+        const int ncyc = until_tol ? max_cycles : mu0;
+        for (int k = 0; k < ncyc; ++k) {
+            MG_TRY(vcycle_graphed(c, l));
+            if (l < top) continue;
+            ++done_cycles;
+            if (!until_tol && !norms) continue;
+            // residual (and error) of this cycle's iterate in the caller's norm (multigrid.py:291-295)
+            double rn = 0.0, en = 0.0;
+            MG_TRY(fmg_norms(c, l, norm, err_hist != nullptr, &rn, &en));
+            if (resid_hist) resid_hist[k] = rn;
+            if (err_hist) err_hist[k] = en;
+            if (until_tol && rn <= tol) break;
         }
     }
     if (cycles_done) *cycles_done = done_cycles;
     return 0;
+}
+
+int mg_fmg(mg_handle c, int top, int mu0, double tol, int max_cycles, double* resid_l2, int* cycles_done) {
+    return mg_fmg_ex(c, top, mu0, tol, max_cycles, MG_NORM_L2, resid_l2, nullptr, cycles_done);
 }
 
 int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double* avg_ms) {
@@ -2329,9 +2477,13 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
     HIP_TRY(hipSetDevice(c->device));
     const std::string k(kernel);
     Level& L = c->L[level];
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     auto once = [&]() -> int {
         if (k == "jacobi") return launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr);
         // "jacobi2": only where mg_smooth itself pairs sweeps on this level; "jacobi2!": wherever the kernel applies
@@ -2353,8 +2505,6 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *avg_ms = (double)ms / reps;
     return 0;
 }

@@ -23,7 +23,7 @@ import scipy.sparse as sp
 
 from .poisson import grid_index_from_coords
 
-__all__ = ["csr_from_petsc", "coordinates_of", "level_from_dolfinx", "bag_from_dolfinx"]
+__all__ = ["csr_from_petsc", "coordinates_of", "level_from_dolfinx", "bag_from_dolfinx", "mass_matrix_of"]
 
 
 def csr_from_petsc(A) -> sp.csr_matrix:
@@ -104,3 +104,27 @@ def bag_from_dolfinx(levels: Dict[int, Sequence], coarsest_level_elements_per_di
         bag.element_size[l] = 1.0 / N
         grid_index[l] = gi
     return bag, grid_index
+
+
+def mass_matrix_of(V) -> sp.csr_matrix:
+    """P1 mass matrix `M_ij = int phi_i phi_j dx` of a dolfinx function space, so that `sqrt(r^T M r)` is the
+    reference's `res_calculator` norm `sqrt(assemble_scalar(r_h * r_h * dx))` (`multigrid.py:203-208`) for the
+    finite-element function with nodal values r.  Needs an importable dolfinx + ufl (2021-era or current API); a
+    SciPy matrix is passed through.  Never run against a real dolfinx build here (not installable offline)."""
+    if sp.issparse(V):
+        return V.tocsr()
+    try:
+        import dolfinx
+        import ufl
+    except ImportError as exc:
+        raise TypeError("V_fine_dolfx is neither a SciPy mass matrix nor usable without dolfinx/ufl: pass the P1 mass "
+                        "matrix of the finest mesh (scipy.sparse) as V_fine_dolfx, or configure(norm='l2')") from exc
+    u, v = ufl.TrialFunction(V), ufl.TestFunction(V)
+    form = u * v * ufl.dx
+    fem = dolfinx.fem
+    if hasattr(fem, "form"):                          # current API
+        A = fem.petsc.assemble_matrix(fem.form(form))
+    else:                                             # the reference's API (Multigrid_prototype.py:92)
+        A = fem.assemble_matrix(form)
+    A.assemble()
+    return csr_from_petsc(A)

@@ -344,14 +344,40 @@ class DeviceHierarchy:
         check(self._lib.mg_set_level_grid(self._h, 0, 0, int(n), None))
         self._flat_n = int(n)
 
-    def fmg(self, mu0: int, tol: float = 0.0, max_cycles: int = 10000, top_level: Optional[int] = None):
-        """FMG on levels coarsest..top_level; returns the l2 residual after every top-level cycle."""
+    def fmg(self, mu0: int, tol: float = 0.0, max_cycles: int = 10000, top_level: Optional[int] = None,
+            norm: str = "l2", errors: bool = False):
+        """FMG on levels coarsest..top_level; returns the residual norm after every top-level cycle -- the l2 norm,
+        or with norm="mass" the reference's L2(Omega) norm sqrt(r^T M r) (set_mass) -- and with `errors` also the
+        norm of iterate - exact solution (set_exact) as a second array.  Everything stays on the device."""
         top = self.finest_level if top_level is None else top_level
         hist = np.zeros(max(mu0, max_cycles if tol > 0 else mu0, 1))
+        ehist = np.zeros_like(hist) if errors else None
         done = C.c_int()
-        check(self._lib.mg_fmg(self._h, self._idx(top), int(mu0), float(tol), int(max_cycles), ptr(hist),
-                               C.byref(done)))
+        check(self._lib.mg_fmg_ex(self._h, self._idx(top), int(mu0), float(tol), int(max_cycles),
+                                  {"l2": _capi.MG_NORM_L2, "mass": _capi.MG_NORM_MASS}[norm], ptr(hist),
+                                  ptr(ehist) if errors else None, C.byref(done)))
+        if errors:
+            return hist[:done.value].copy(), ehist[:done.value].copy()
         return hist[:done.value].copy()
+
+    def set_mass(self, level: int, M):
+        """The P1 mass matrix of `level` (SciPy CSR, the level's DoF numbering) for the L2(Omega) norms of fmg."""
+        indptr, is64, indices, data = _csr_arrays(M)
+        check(self._lib.mg_set_mass_csr(self._h, self._idx(level), M.shape[0], data.size, ptr(indptr), is64,
+                                        ptr(indices), ptr(data)))
+
+    def set_exact(self, level: int, u):
+        """Nodal values of the exact solution on `level` (error history of fmg)."""
+        a = _capi.as_f64(u, self.n_dofs(level))
+        check(self._lib.mg_set_exact(self._h, self._idx(level), ptr(a)))
+
+    def counters(self) -> dict:
+        """Whole-vector host <-> device copies, replayed / cached V-cycle graphs so far (tests)."""
+        up, down, rep = C.c_int64(), C.c_int64(), C.c_int64()
+        cached = C.c_int()
+        check(self._lib.mg_counters(self._h, C.byref(up), C.byref(down), C.byref(rep), C.byref(cached)))
+        return {"uploads": int(up.value), "downloads": int(down.value), "graph_replays": int(rep.value),
+                "graphs_cached": int(cached.value)}
 
     def set_level_grid(self, level: int, grid_index=None):
         """Geometry + numbering only (transfer operators without a matrix)."""

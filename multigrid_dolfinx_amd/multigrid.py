@@ -15,9 +15,12 @@ Differences from the reference, all documented in DESIGN.md:
     one-matrix form `v + w D^-1 (f - A v)` (identical to the split form to ~2e-16 per
     sweep); the `A_h` argument selects the level (`A_h[2]`), as `A_sp_dict` already does
     for the residual and the coarsest solve in the reference (`multigrid.py:239`, `:244`);
-  * the coarsest level is solved by a device PCG to 1e-14 instead of SuperLU;
-  * the stop test of `FullMultiGrid` uses the l2 norm (or `sqrt(r^T M r)` for a mass
-    matrix given to `configure`) because dolfinx's assembled norm is not available.
+  * the coarsest level is solved exactly by a block-tridiagonal LU on the device (Jacobi-PCG to
+    1e-14 where the blocks would not fit) instead of SuperLU;
+  * the stop test and the histories of `FullMultiGrid` use the reference's L2(Omega) norm as
+    `sqrt(r^T M r)` with the P1 mass matrix M of the finest mesh given as `V_fine_dolfx` (or
+    assembled from a dolfinx function space by `dolfinx_adapter.mass_matrix_of`); the Euclidean
+    norm only on request (`configure(norm="l2")`, or `V_fine_dolfx = None`).
 Results agree with the reference to <= 1e-10 relative l2 (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
@@ -50,11 +53,44 @@ V_fine_dolfx = None
 
 # ---- state of this implementation --------------------------------------------------------------------
 _options = {"dim": 2, "prune_zeros": True, "device": 0, "restriction": "direct", "smoother": "jacobi",
-            "grid_index": None,
+            "grid_index": None, "norm": "auto",
             "coarse_rtol": 1e-14, "stop_tol": 1e-11, "max_cycles": 10000, "tuning": {}}
 _hier = None            # DeviceHierarchy of the initialised problem
-_grid_cache = {}        # id(mesh dict) -> (dict, grid_index, N)
-_adhoc = {}             # small cache of stand-alone device contexts (transfers / smoother)
+_hier_params = None     # the parameter tuple last sent to it (mg_set_params only when it changes)
+_CACHE_MAX = 8
+
+
+class _LRU(dict):
+    """Bounded cache of device contexts / grid indices: the least recently used entry goes first and is closed."""
+
+    def __init__(self, close=None):
+        super().__init__()
+        self._close = close
+
+    def lookup(self, key):
+        hit = self.get(key)
+        if hit is not None:
+            self[key] = self.pop(key)           # most recently used last
+        return hit
+
+    def store(self, key, value):
+        self.pop(key, None)
+        while len(self) >= _CACHE_MAX:
+            old = self.pop(next(iter(self)))
+            if self._close:
+                self._close(old)
+        self[key] = value
+        return value
+
+    def drop_all(self):
+        while self:
+            old = self.pop(next(iter(self)))
+            if self._close:
+                self._close(old)
+
+
+_grid_cache = _LRU()                                    # id(mesh dict) -> (dict, grid_index, N)
+_adhoc = _LRU(close=lambda hit: _release(hit[0]))       # stand-alone device contexts (transfers / smoother / norms)
 
 
 def configure(**kw):
@@ -62,14 +98,17 @@ def configure(**kw):
     `restriction` ('direct' = the live path, or 'full_weighting'), `smoother` ('jacobi' = the
     reference's, or 'rbgs' = red-black Gauss-Seidel with `omega` as SOR factor), `grid_index`
     ({level: lexicographic node index per DoF}, instead of coordinate dictionaries),
-    `coarse_rtol`, `stop_tol`, `max_cycles`, `tuning` (kernel knobs)."""
-    global _hier
+    `norm` ('auto': the reference's L2(Omega) norm through the mass matrix `V_fine_dolfx`, the l2 norm when that is
+    None; 'l2': always the l2 norm), `coarse_rtol`, `stop_tol`, `max_cycles`, `tuning` (kernel knobs)."""
+    global _hier, _hier_params
     for k, v in kw.items():
         if k not in _options:
             raise KeyError(f"unknown option {k}")
         _options[k] = v
     _release(_hier)
-    _hier = None
+    _hier = _hier_params = None
+    _adhoc.drop_all()
+    _grid_cache.drop_all()
 
 
 def _release(h):
@@ -82,7 +121,7 @@ def initialize_problem(obj):
     (re)built on the next hot-path call."""
     global mesh_dof_list_dict, element_size, coarsest_level_elements_per_dim, coarsest_level, finest_level
     global A_sp_dict, A_jacobi_sp_dict, b_dict, mu0, mu1, mu2, omega, residual_per_V_cycle_finest
-    global error_per_V_cycle_finest, u_exact_fine, V_fine_dolfx, _hier
+    global error_per_V_cycle_finest, u_exact_fine, V_fine_dolfx, _hier, _hier_params
     mesh_dof_list_dict = obj.mesh_dof_list_dict
     element_size = obj.element_size
     coarsest_level_elements_per_dim = obj.coarsest_level_elements_per_dim
@@ -100,25 +139,27 @@ def initialize_problem(obj):
     u_exact_fine = obj.u_exact_fine
     V_fine_dolfx = obj.V_fine_dolfx
     _release(_hier)
-    _hier = None
+    _hier = _hier_params = None
+    _adhoc.drop_all()
+    _grid_cache.drop_all()
 
 
 def _grid_index_of(mesh_dict, N, dim):
     """Lexicographic node index per DoF from a reference coordinate dictionary."""
     key = id(mesh_dict)
-    hit = _grid_cache.get(key)
+    hit = _grid_cache.lookup(key)
     if hit is not None and hit[0] is mesh_dict and hit[2] == N:
         return hit[1]
     n = (N + 1) ** dim
     coords = np.array([mesh_dict[j] for j in range(n)], dtype=np.float64)
     gi = grid_index_from_coords(coords, N, dim)
-    _grid_cache[key] = (mesh_dict, gi, N)
+    _grid_cache.store(key, (mesh_dict, gi, N))
     return gi
 
 
 def _hierarchy():
     """The device hierarchy of the initialised problem (built once)."""
-    global _hier
+    global _hier, _hier_params
     if A_sp_dict is None:
         raise RuntimeError("initialize_problem has not been called")
     if _hier is None:
@@ -132,9 +173,13 @@ def _hierarchy():
             elif mesh_dof_list_dict:
                 gi = _grid_index_of(mesh_dof_list_dict[level], h.elements(level), dim)
             h.set_level(level, A_sp_dict[level][0], gi, prune_zeros=_options["prune_zeros"])
-        _hier = h
-    _hier.set_params(mu1, mu2, omega, restriction=_options["restriction"],
-                     coarse_rtol=_options["coarse_rtol"], keep_err=True, smoother=_options["smoother"])
+        _hier, _hier_params = h, None
+    # the parameters go to the device only when they change (the captured V-cycle graphs depend on them)
+    params = (mu1, mu2, omega, _options["restriction"], _options["coarse_rtol"], _options["smoother"])
+    if params != _hier_params:
+        _hier.set_params(mu1, mu2, omega, restriction=_options["restriction"],
+                         coarse_rtol=_options["coarse_rtol"], keep_err=True, smoother=_options["smoother"])
+        _hier_params = params
     return _hier
 
 
@@ -157,15 +202,13 @@ def _transfer_context(mesh_dict_coarse, mesh_dict_fine, n_coarse, n_fine):
     if (Nc + 1) ** dim != n_coarse or (Nf + 1) ** dim != n_fine or Nf != 2 * Nc:
         raise ValueError("vector sizes do not describe two nested (N+1)^dim grids")
     key = ("xfer", id(mesh_dict_coarse), id(mesh_dict_fine), Nc)
-    hit = _adhoc.get(key)
+    hit = _adhoc.lookup(key)
     if hit is not None and hit[1] is mesh_dict_coarse and hit[2] is mesh_dict_fine:
         return hit[0]
     h = DeviceHierarchy(dim, 0, 1, c=Nc, device=_options["device"])
     h.set_level_grid(0, _grid_index_of(mesh_dict_coarse, Nc, dim))
     h.set_level_grid(1, _grid_index_of(mesh_dict_fine, Nf, dim))
-    if len(_adhoc) >= 8:
-        _release(_adhoc.pop(next(iter(_adhoc)))[0])
-    _adhoc[key] = (h, mesh_dict_coarse, mesh_dict_fine)
+    _adhoc.store(key, (h, mesh_dict_coarse, mesh_dict_fine))
     return h
 
 
@@ -208,23 +251,28 @@ def res_calculator(res, V_space):
     r = _column(res)
     if V_space is None:
         key = ("l2", r.shape[0])
-        hit = _adhoc.get(key)
+        hit = _adhoc.lookup(key)
         if hit is None:
             h = DeviceHierarchy(_options["dim"], 0, 0, c=1, device=_options["device"])
             h.set_flat_space(r.shape[0])
-            hit = _adhoc[key] = (h, None, None)
+            hit = _adhoc.store(key, (h, None, None))
         hit[0].set_vector(0, "v", r)
         return hit[0].norm2(0, "v")
-    if sp.issparse(V_space):
-        key = ("mass", id(V_space))
-        hit = _adhoc.get(key)
+    if not sp.issparse(V_space):
+        from .dolfinx_adapter import mass_matrix_of
+        key = ("massof", id(V_space))
+        hit = _adhoc.lookup(key)
         if hit is None or hit[1] is not V_space:
-            h = DeviceHierarchy(_options["dim"], 0, 0, c=1, device=_options["device"])
-            h.set_flat_level(V_space.tocsr(), prune_zeros=True)
-            hit = _adhoc[key] = (h, V_space, None)
-        hit[0].set_vector(0, "v", r)
-        return float(np.sqrt(hit[0].quadratic_form(0, "v")))
-    raise NotImplementedError("dolfinx function spaces are not available; pass a mass matrix or None")
+            hit = _adhoc.store(key, (None, V_space, mass_matrix_of(V_space)))     # raises without dolfinx
+        V_space = hit[2]
+    key = ("mass", id(V_space))
+    hit = _adhoc.lookup(key)
+    if hit is None or hit[1] is not V_space:
+        h = DeviceHierarchy(_options["dim"], 0, 0, c=1, device=_options["device"])
+        h.set_flat_level(V_space.tocsr(), prune_zeros=True)
+        hit = _adhoc.store(key, (h, V_space, None))
+    hit[0].set_vector(0, "v", r)
+    return float(np.sqrt(hit[0].quadratic_form(0, "v")))
 
 
 def err_calculator(u, u_exact, V_space):
@@ -239,16 +287,14 @@ def _smoother_context(A):
     problem: the two operands go to the device as they are and the sweeps run in the reference's split
     form (`mg_smooth_split`)."""
     key = ("jac", id(A[0]))
-    hit = _adhoc.get(key)
+    hit = _adhoc.lookup(key)
     if hit is not None and hit[1] is A[0]:
         return hit[0]
     h = DeviceHierarchy(_options["dim"], 0, 0, c=1, device=_options["device"])
     h.set_tuning("require_diagonal", 0)
     h.set_flat_level(A[0].tocsr() if not sp.isspmatrix_csr(A[0]) else A[0])
     h.set_vector(0, "err", A[1].diagonal())
-    if len(_adhoc) >= 8:
-        _release(_adhoc.pop(next(iter(_adhoc)))[0])
-    _adhoc[key] = (h, A[0], None)
+    _adhoc.store(key, (h, A[0], None))
     return h
 
 
@@ -287,7 +333,7 @@ def V_cycle_scheme(A_h, v_h, f_h, test=False):
     return out
 
 
-def _fmg(level, f_h, cycles_tol):
+def _fmg(level, f_h, cycles_tol, norm="l2", errors=False):
     h = _hierarchy()
     for l in range(coarsest_level, level):
         h.set_rhs_true(l, b_dict[l])
@@ -295,43 +341,57 @@ def _fmg(level, f_h, cycles_tol):
     if level == coarsest_level:
         h.coarse_solve()
         return h, np.zeros(0)
-    return h, h.fmg(mu0, tol=cycles_tol, max_cycles=_options["max_cycles"], top_level=level)
+    return h, h.fmg(mu0, tol=cycles_tol, max_cycles=_options["max_cycles"], top_level=level, norm=norm, errors=errors)
+
+
+_mass_on_device = None      # (hierarchy, V_fine_dolfx object) whose mass matrix the hierarchy holds
+
+
+def _finest_norm(h):
+    """Which norm `FullMultiGrid` stops on, with the mass matrix handed to the device once: 'mass' = the
+    reference's L2(Omega) norm (multigrid.py:203-208, :292-296), 'l2' only when asked for or when no space was given."""
+    global _mass_on_device
+    if _options["norm"] == "l2" or V_fine_dolfx is None:
+        return "l2"
+    if _options["norm"] != "auto":
+        raise ValueError("configure(norm=...) must be 'auto' or 'l2'")
+    if _mass_on_device is None or _mass_on_device[0] is not h or _mass_on_device[1] is not V_fine_dolfx:
+        from .dolfinx_adapter import mass_matrix_of
+        M = mass_matrix_of(V_fine_dolfx)        # raises TypeError for a space that cannot be assembled here
+        h.set_mass(finest_level, M)
+        _mass_on_device = (h, V_fine_dolfx)
+    return "mass"
 
 
 def FullMultiGrid(A_h, f_h):
     """Full multigrid (`multigrid.py:271-307`): below the finest level `mu0` V-cycles per level, on the
-    finest level V-cycles until the residual norm is <= 1e-11 (`:296`).  The norm is the l2 norm, or -- when
-    `V_fine_dolfx` holds the P1 mass matrix of the finest mesh instead of a dolfinx function space -- the
-    reference's L2(Omega) norm `sqrt(r^T M r)`, with `u_exact_fine` (nodal values) feeding the error history
-    exactly as `:292-293` does.  Appends the
-    per-cycle residual norm to `residual_per_V_cycle_finest` and the iteration count to
-    `iter_count_for_diff_num_elems_<levels>_levels.csv`, as the reference does (`:295-301`)."""
+    finest level V-cycles until the residual norm is <= 1e-11 (`:296`), all on the device (`mg_fmg_ex`: per cycle
+    two doubles return to the host).  The norm is the reference's L2(Omega) norm `sqrt(r^T M r)` with the P1 mass
+    matrix of the finest mesh: `V_fine_dolfx` is that matrix (SciPy) or a dolfinx function space it is assembled
+    from (`dolfinx_adapter.mass_matrix_of`; an error if dolfinx is not importable -- never a silent change of
+    norm).  With `V_fine_dolfx = None` or `configure(norm="l2")` it is the l2 norm, which is about 1/h stricter in
+    2-D for the same tolerance.  `u_exact_fine` (nodal values) feeds `error_per_V_cycle_finest` every cycle as
+    `:292-293` does, in the same norm.  Appends the per-cycle residual norm to `residual_per_V_cycle_finest` and the
+    iteration count to `iter_count_for_diff_num_elems_<levels>_levels.csv`, as the reference does (`:295-301`)."""
     level = A_h[2]
     on_finest = level == finest_level
-    if on_finest and level > coarsest_level and sp.issparse(V_fine_dolfx):
-        # the reference's own stop test: L2(Omega) norms through `res_calculator` / `err_calculator`
-        # (multigrid.py:288-296), with the P1 mass matrix standing in for the dolfinx function space
-        h, _ = _fmg(level - 1, b_dict[level - 1], 0.0)
-        h.set_vector(level, "f", _column(f_h))
-        h.prolong(level, add=False)
-        h.copy_vector(level, "v", "err")
-        hist = []
-        for _ in range(_options["max_cycles"]):
-            h.vcycle(level, 1)
-            h.residual(level)
-            if u_exact_fine is not None and error_per_V_cycle_finest is not None:
-                error_per_V_cycle_finest.append(err_calculator(h.get_vector(level, "v"), u_exact_fine, V_fine_dolfx))
-            hist.append(res_calculator(h.get_vector(level, "r"), V_fine_dolfx))
-            if hist[-1] <= _options["stop_tol"]:
-                break
-    else:
-        h, hist = _fmg(level, f_h, _options["stop_tol"] if on_finest else 0.0)
     if on_finest and level > coarsest_level:
+        h = _hierarchy()
+        norm = _finest_norm(h)
+        errors = u_exact_fine is not None and error_per_V_cycle_finest is not None
+        if errors:
+            h.set_exact(level, _column(u_exact_fine))
+        h, out = _fmg(level, f_h, _options["stop_tol"], norm=norm, errors=errors)
+        hist, ehist = out if errors else (out, None)
+        if errors:
+            error_per_V_cycle_finest.extend(float(x) for x in ehist)
         if residual_per_V_cycle_finest is not None:
             residual_per_V_cycle_finest.extend(float(x) for x in hist)
         with open(f'iter_count_for_diff_num_elems_{finest_level - coarsest_level + 1}_levels.csv', mode='a') as fh:
             csv.writer(fh, delimiter=',').writerow(
                 [coarsest_level_elements_per_dim * 2 ** finest_level, len(hist)])
+    else:
+        h, _ = _fmg(level, f_h, 0.0)
     return h.get_vector(level, "v")
 
 

@@ -33,9 +33,11 @@ FULL = ["c1_lex", "c1_perm"]
 def mg():
     """The drop-in module with clean state."""
     from multigrid_dolfinx_amd import multigrid as m
-    m.configure(dim=2, prune_zeros=True, restriction="direct", grid_index=None, tuning={})
+    clean = dict(dim=2, prune_zeros=True, restriction="direct", smoother="jacobi", grid_index=None, tuning={}, norm="auto",
+                 stop_tol=1e-11, max_cycles=10000)
+    m.configure(**clean)
     yield m
-    m.configure(dim=2, prune_zeros=True, restriction="direct", grid_index=None, tuning={})
+    m.configure(**clean)
 
 
 def _init_from_fixture(m, name, with_dicts=True):
@@ -766,6 +768,102 @@ def test_full_multigrid_with_the_reference_norms(mg, tmp_path, monkeypatch):
     e = u - lvl.exact()
     assert abs(err[-1] - float(np.sqrt((e.T @ (M @ e)).item()))) <= 1e-9
     assert err[-1] < err[0]
+
+
+def _p1_mass_matrix(lvl, N):
+    """P1 mass matrix of the right-diagonal unit-square mesh in the level's DoF numbering."""
+    import scipy.sparse as sps
+    h = 1.0 / N
+    ij = np.rint(lvl.coords[:, :2] * N).astype(int)
+    node = {(i, j): d for d, (i, j) in enumerate(map(tuple, ij))}
+    rows, cols, vals = [], [], []
+    loc = (h * h / 24.0) * (np.ones((3, 3)) + np.eye(3))
+    for j in range(N):
+        for i in range(N):
+            for tri in (((i, j), (i + 1, j), (i + 1, j + 1)), ((i, j), (i + 1, j + 1), (i, j + 1))):
+                t = [node[p] for p in tri]
+                for a in range(3):
+                    for b in range(3):
+                        rows.append(t[a]); cols.append(t[b]); vals.append(loc[a, b])
+    M = sps.csr_matrix((vals, (rows, cols)), shape=(lvl.n, lvl.n))
+    M.sum_duplicates()
+    return M
+
+
+def test_full_multigrid_keeps_its_norms_on_the_device(mg, tmp_path, monkeypatch):
+    """multigrid.py:288-302 on the device (mg_fmg_ex): however many cycles the stop test takes, the same number of
+    whole vectors crosses PCIe (hand-over of b_dict / f / u_exact, the result) -- per cycle only two doubles do."""
+    monkeypatch.chdir(tmp_path)
+    counts = []
+    for tol in (1e-4, 1e-9):
+        bag = poisson.make_hierarchy(2, 1, 3, c=4, mu0=2, mu1=4, mu2=4, seed=2, with_dicts=True)
+        for l, a in bag.A_sp_dict.items():
+            bag.A_jacobi_sp_dict[l] = mg.getJacobiMatrices(a)
+        bag.V_fine_dolfx = _p1_mass_matrix(bag.levels[3], 32)
+        bag.u_exact_fine = bag.levels[3].exact()
+        mg.configure(restriction="full_weighting", stop_tol=tol)
+        mg.initialize_problem(bag)
+        mg.FullMultiGrid(bag.A_jacobi_sp_dict[3], bag.b_dict[3])
+        c = mg._hierarchy().counters()
+        counts.append((len(bag.residual_per_V_cycle_finest), c["uploads"], c["downloads"]))
+        assert len(bag.error_per_V_cycle_finest) == len(bag.residual_per_V_cycle_finest)
+    (n1, up1, down1), (n2, up2, down2) = counts
+    assert n2 > n1 + 2, counts
+    assert (up1, down1) == (up2, down2), counts
+    assert up1 <= 6 and down1 <= 2, counts
+
+
+def test_full_multigrid_never_changes_norm_silently(mg, tmp_path, monkeypatch):
+    """A `V_fine_dolfx` that is neither None nor a SciPy mass matrix is a dolfinx function space in the reference
+    (multigrid.py:292-296).  Without dolfinx its mass matrix cannot be assembled: that is an error, not a switch to
+    the l2 norm (whose 1e-11 is a different stop test).  `configure(norm="l2")` asks for the l2 norm explicitly, and
+    then the error history is still written every cycle."""
+    monkeypatch.chdir(tmp_path)
+    bag = poisson.make_hierarchy(2, 1, 3, c=4, mu0=2, mu1=4, mu2=4, seed=2, with_dicts=True)
+    for l, a in bag.A_sp_dict.items():
+        bag.A_jacobi_sp_dict[l] = mg.getJacobiMatrices(a)
+    bag.V_fine_dolfx = object()
+    bag.u_exact_fine = bag.levels[3].exact()
+    mg.configure(restriction="full_weighting", stop_tol=1e-8)
+    mg.initialize_problem(bag)
+    with pytest.raises(TypeError):
+        mg.FullMultiGrid(bag.A_jacobi_sp_dict[3], bag.b_dict[3])
+    mg.configure(restriction="full_weighting", stop_tol=1e-8, norm="l2")
+    mg.initialize_problem(bag)
+    u = mg.FullMultiGrid(bag.A_jacobi_sp_dict[3], bag.b_dict[3])
+    res, err = bag.residual_per_V_cycle_finest, bag.error_per_V_cycle_finest
+    assert len(res) == len(err) >= 1 and res[-1] <= 1e-8
+    r = bag.b_dict[3] - bag.A_sp_dict[3][0].dot(u)
+    assert abs(res[-1] - np.linalg.norm(r)) <= 1e-6 * res[-1] + 1e-15
+    assert abs(err[-1] - np.linalg.norm(u - bag.levels[3].exact())) <= 1e-9
+
+
+def test_shim_replays_the_captured_cycle(mg):
+    """`V_cycle_scheme` through the drop-in module sets the same parameters before every call: that must not
+    invalidate the captured V-cycle (mg_set_params only counts real changes), so the second call replays it."""
+    g, bag = _init_from_fixture(mg, "c1_lex")
+    f = bag.b_dict[3]
+    v = np.zeros_like(f)
+    for _ in range(3):
+        v = mg.V_cycle_scheme(bag.A_jacobi_sp_dict[3], v, f)
+    c = mg._hierarchy().counters()
+    assert c["graphs_cached"] == 1 and c["graph_replays"] == 2, c
+    mg._hierarchy().set_params(50, 50, 0.5)                 # a real change: new capture
+    mg._hier_params = None
+    mg.V_cycle_scheme(bag.A_jacobi_sp_dict[3], v, f)
+    assert mg._hierarchy().counters()["graphs_cached"] >= 1
+
+
+def test_adhoc_contexts_are_bounded(mg):
+    """Stand-alone contexts (norms of vectors of many lengths, transfers between many mesh pairs) live in one
+    bounded LRU cache; `configure` / `initialize_problem` drop them."""
+    rng = np.random.default_rng(0)
+    for n in range(40, 60):
+        r = rng.standard_normal((n, 1))
+        assert abs(mg.res_calculator(r, None) - np.linalg.norm(r)) <= 1e-13 * np.linalg.norm(r)
+    assert len(mg._adhoc) <= 8
+    mg.configure(dim=2)
+    assert len(mg._adhoc) == 0 and len(mg._grid_cache) == 0
 
 
 @pytest.mark.parametrize("c,lo,hi", [(8, 2, 4), (5, 1, 3), (7, 1, 4)])
