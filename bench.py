@@ -324,6 +324,13 @@ def main():
         pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
     except Exception:
         pair_ms = None
+    multi_k = 0
+    if pair_ms is None:
+        try:    # 2-D levels with row classes: up to five sweeps per launch (sdia_jacobik2d)
+            pair_ms = h.time_kernel("jacobik", hi, args.kernel_reps)
+            multi_k = next((int(kv.split("=")[1]) for kv in args.tune if kv.startswith("fuse_2d_k=")), 5)
+        except Exception:
+            pair_ms = None
     user_tuning = bool(args.tune) or any(v is not None for v in (
         args.rows_per_lane, args.xcd_chunk, args.offset_codes, args.strip_slices, args.nontemporal,
         args.symmetric_storage, args.lds_pad))
@@ -342,7 +349,7 @@ def main():
             return 8 * W + 8 * ((W + 7) // 8) + 24
         return 12 * W + 32
 
-    sweeps_per_launch = 2 if pair_ms else 1
+    sweeps_per_launch = (multi_k or 2) if pair_ms else 1
     dom_ms = pair_ms if pair_ms else jac_ms
     dom_classes = classes_in_pair if pair_ms else classes_in_sweep
     fmt_row = format_bytes_per_row(dom_classes)
@@ -351,7 +358,9 @@ def main():
     # SURVEY.md 8(d)'s CSR byte model of the same work, for comparison only (never a roofline fraction: the shipped
     # formats do not move these bytes)
     csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
-    if pair_ms:
+    if multi_k:
+        kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
+    elif pair_ms:
         kernel_id = ("sdia_jacobi2c_finest<12, 2>" if dom_classes else "sdia_jacobi2_finest<2, 8, 2, false>")
     elif info["symmetric_diagonals"]:
         kernel_id = ("sdia_cls_jacobi_finest<%d, 2, true>" % info["symmetric_diagonals"]) if dom_classes else \
@@ -386,7 +395,7 @@ def main():
         try:
             k_plain = max(1, min(args.steps, 5))
             value_plain = k_plain / timed_cycles(h, rv, hi, 1, k_plain)
-            if pair_ms:
+            if pair_ms and not multi_k:
                 pair_plain_ms = h.time_kernel("jacobi2", hi, max(2, args.kernel_reps // 2))
         finally:
             h.set_tuning("fuse_classes", 1)
@@ -417,7 +426,7 @@ def main():
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": kernel_id + (" (two fine-level weighted-Jacobi sweeps per launch" if pair_ms else
+                         "kernel": kernel_id + (f" ({sweeps_per_launch} fine-level weighted-Jacobi sweeps per launch" if pair_ms else
                                                 " (one fine-level weighted-Jacobi sweep per launch") +
                                    (", class-coded rows)" if dom_classes else ")"),
                          "bytes_model": (f"{fmt_row} B per row and launch = what the shipped format must stream: "

@@ -166,6 +166,9 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "fuse_even"          1 = the tile columns of the class-coded pass are equally wide, as narrow as covers the grid;
  *                          0 = always 124 cells, the last column nearly empty (0: measured faster); bit-identical
  *     "fuse_wi"            experiments: that width given directly (0 = chosen per level as above)
+ *     "fuse_2d"            up to "fuse_2d_k" Jacobi sweeps per launch on 2-D five-point levels with row classes (1);
+ *                          bit-identical to single sweeps
+ *     "fuse_2d_k"          ... at most this many per launch, 2..5 (5)
  *     "fuse_xcd_chunk"     consecutive tiles of that pass given to one XCD at a time (32)
  *     "cls_blocks_per_cu"  persistent blocks per CU of the one-sweep class kernels (4)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
@@ -251,7 +254,8 @@ int mg_counters(mg_handle h, int64_t* uploads, int64_t* downloads, int64_t* grap
  * mg_time_kernel: average duration in milliseconds of `reps` back-to-back launches of
  * one kernel of the path on `level`, measured with HIP events on the handle's own
  * stream ("jacobi", "residual", "restrict", "prolong", "norm2"; "jacobi2" = the two-sweep pass, an
- * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies).
+ * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies;
+ * "jacobik" = one launch of the K-sweep 2-D kernel with K = "fuse_2d_k", an error on levels that do not use it).
  * Used by bench.py for the roofline figure.  mg_sync waits for the handle's stream. */
 int mg_time_kernel(mg_handle h, const char* kernel, int level, int reps, double* avg_ms);
 int mg_sync(mg_handle h);

@@ -231,6 +231,8 @@ struct mg_context {
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     int fuse_wi = 0;                // experiments: cells per tile line with a second sweep (0: chosen per level)
     int fuse_even = 0;              // all tile columns of the class-coded pass equally wide (measured slower: more full tiles, same bytes)
+    int fuse_2d = 1;                // K sweeps per launch on 2-D levels with row classes (sdia_jacobik2d)
+    int fuse_2d_k = 5;              // ... at most this many (2..5)
     int fuse_xcd_chunk = 32;        // consecutive tiles of that pass per XCD at a time
     int cls_blocks_per_cu = 4;      // persistent blocks of the one-sweep class kernels (72 VGPRs, 94 SGPRs admit 7)
     DirectSolver direct;
@@ -902,6 +904,44 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
 }
 
+// K sweeps per launch on 2-D levels (mg_jacobi2.hip.h, sdia_jacobik2d): whole, undistributed five-point levels
+// with row classes whose stored diagonals are exactly {0, +1, +nx}.
+bool sweeps2d_ok(const mg_context* c, const Level& L) {
+    if (!c->fuse_2d || !L.sdia || L.wu != 3 || !L.cls || !c->fuse_classes || L.flat || !L.replicated) return false;
+    return L.g.ny == 1 && L.up[1] == 1 && L.up[2] == L.g.nx && L.g.nx >= 8 && L.g.nz >= 8;
+}
+
+constexpr int kJKLines = 40;
+
+template <int K>
+int launch_jacobik_t(mg_context* c, const JKArgs& a) {
+    constexpr size_t lds = jk_lds_bytes<kJKLines>();
+    void (*const kern)(JKArgs) = sdia_jacobik2d<K, kJKLines>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), lds));
+    JKArgs b = a;
+    b.ntx = (a.nx + JK_W - 2 * K - 1) / (JK_W - 2 * K);
+    b.nty = (a.nlines + kJKLines - 2 * K - 1) / (kJKLines - 2 * K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(b.ntx * b.nty)), dim3(1024), lds, c->stream, b);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out = K Jacobi sweeps applied to x (2 <= K <= 5)
+int launch_jacobik(mg_context* c, const Level& L, int K, const double* x_rows, const double* f_rows, double* out_rows) {
+    JKArgs a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.cls = L.cls + L.cls_lead; a.ctab = L.ctab; a.ncls = L.ncls; a.cmain = L.cmain;
+    for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+    a.n = L.nloc; a.nx = L.g.nx; a.nlines = L.g.nz; a.omega = c->omega;
+    switch (K) {
+        case 2: return launch_jacobik_t<2>(c, a);
+        case 3: return launch_jacobik_t<3>(c, a);
+        case 4: return launch_jacobik_t<4>(c, a);
+        case 5: return launch_jacobik_t<5>(c, a);
+        default: return fail("sweeps per launch must be in 2..5");
+    }
+}
+
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
@@ -918,6 +958,18 @@ int smooth(mg_context* c, int level, int nw) {
         return 0;
     }
     const bool dist = !L.replicated && c->comm.active();
+    if (!dist && sweeps2d_ok(c, L)) {
+        // 2-D levels: up to fuse_2d_k sweeps per launch, the rest (at most one) as a single sweep
+        int left = nw;
+        while (left >= 2) {
+            int k = std::min(c->fuse_2d_k, left);
+            if (left - k == 1 && k > 2) --k;                // 6 = 3 + 3 rather than 5 + 1
+            MG_TRY(launch_jacobik(c, L, k, L.v.rows, L.f.rows, L.v2.rows));
+            std::swap(L.v, L.v2);
+            left -= k;
+        }
+        nw = left;
+    }
     // slices that hold rows of the first / last owned plane: their results are what the neighbours need
     const int64_t S = (int64_t)WAVE * L.R;
     const int64_t lo_end = std::min(L.nslices, (L.g.plane + S - 1) / S);
@@ -1844,6 +1896,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_shape") {
         if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
+    } else if (k == "fuse_2d") {
+        c->fuse_2d = value != 0;
+    } else if (k == "fuse_2d_k") {
+        if (value < 2 || value > 5) return fail("fuse_2d_k must be in 2..5");
+        c->fuse_2d_k = (int)value;
     } else if (k == "fuse_xcd_chunk") {
         if (value < 1 || value > 512) return fail("fuse_xcd_chunk must be in 1..512");
         c->fuse_xcd_chunk = (int)value;
@@ -2491,6 +2548,10 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             if (!fused_sweeps_ok(c, L, k == "jacobi2!")) return fail("level does not use the two-sweep kernel");
             const J2Plan plan = jacobi2_plan(c, L, false, 0);
             return launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows);
+        }
+        if (k == "jacobik") {
+            if (!sweeps2d_ok(c, L)) return fail("level does not use the K-sweep 2-D kernel");
+            return launch_jacobik(c, L, c->fuse_2d_k, L.v.rows, L.f.rows, L.v2.rows);
         }
         if (k == "residual") return residual(c, level);
         if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");

@@ -748,3 +748,119 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2_finest(J2Args a) {
 }
 
 }  // namespace mgk
+
+namespace mgk {
+
+// ---- K sweeps in one launch on 2-D levels (five-point rows through row classes) --------------------------------
+// The reference's own configurations are 2-D (Multigrid_prototype.py:35-46: 64 x 64, V(50,50)); a 2-D level is a few
+// MB at most, so its sweeps are launch- and latency-bound, not bandwidth-bound.  Here a 1024-thread workgroup loads
+// a region of 128 x H cells (x, f and the class bytes: 17 bytes per cell) into LDS, relaxes it K times there -- the
+// region that is still exact shrinks by one ring per sweep -- and stores the inner (128 - 2K) x (H - 2K) cells:
+// one launch and one pass over memory for K sweeps.  Everything is done in ROW space like the 3-D pass (cell
+// (ex, ey) <-> row (ty0+ey)*nx + tx0+ex whether or not that wraps around a grid line; rows outside the level are
+// zeros), with the arithmetic of sdia_cls_body<3, ...>: bit-identical to K single sweeps.
+struct JKArgs {
+    const double* x;        // row-based
+    const double* f;
+    double* out;            // != x
+    const unsigned char* cls;       // row-based
+    const double* ctab;
+    int ncls, cmain;
+    double cm[8];
+    int64_t n;              // rows of the level
+    int nx, nlines;         // grid: nx columns, nlines lines (row = line * nx + column)
+    int ntx, nty;
+    double omega;
+};
+
+constexpr int JK_W = 128;
+
+template <int H> constexpr size_t jk_lds_bytes() { return (size_t)H * JK_W * (3 * sizeof(double) + 1) + 256 * CLS_W * sizeof(double); }
+
+template <int K, int H>
+__global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
+    constexpr int W = JK_W, NT = 1024, CELLS = W * H;
+    static_assert(CELLS % NT == 0, "whole rounds of the workgroup");
+    extern __shared__ double j2_smem[];
+    double* const sT = j2_smem;                               // 256 x 8 (classes in use), [7] = omega / diagonal
+    double* const sX = sT + 256 * CLS_W;                      // 2 x CELLS
+    double* const sF = sX + 2 * CELLS;                        // CELLS
+    unsigned char* const sC = reinterpret_cast<unsigned char*>(sF + CELLS);
+    const int tid = threadIdx.x;
+    const int tix = (int)(blockIdx.x % (unsigned)a.ntx), tiy = (int)(blockIdx.x / (unsigned)a.ntx);
+    const int tx0 = tix * (W - 2 * K) - K, ty0 = tiy * (H - 2 * K) - K;       // grid position of cell (0, 0)
+    const int64_t r00 = (int64_t)ty0 * a.nx + tx0;
+
+    // ---- region -> LDS (rows outside the level: zeros, class 0) ----
+#pragma unroll
+    for (int i = 0; i < CELLS / NT; ++i) {
+        const int idx = tid + i * NT;
+        const int64_t row = r00 + (int64_t)(idx / W) * a.nx + (idx % W);
+        const bool ok = row >= 0 && row < a.n;
+        sX[idx] = ok ? a.x[row] : 0.0;
+        sF[idx] = ok ? a.f[row] : 0.0;
+        sC[idx] = ok ? a.cls[row] : (unsigned char)0;
+    }
+    for (int i = tid; i < a.ncls * CLS_W; i += NT) {
+        double v = a.ctab[i];
+        if ((i & (CLS_W - 1)) == CLS_W - 1) {
+            const double d = a.ctab[i - 4];
+            v = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+        }
+        sT[i] = v;
+    }
+    const double m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5];
+    const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    __syncthreads();
+
+    // ---- K sweeps in LDS: sweep s is exact on [s, W-s) x [s, H-s) ----
+#pragma unroll
+    for (int s = 1; s <= K; ++s) {
+        const double* const src = sX + ((s - 1) & 1) * CELLS;
+        double* const dst = sX + (s & 1) * CELLS;
+#pragma unroll
+        for (int i = 0; i < CELLS / NT; ++i) {
+            const int idx = tid + i * NT;
+            const int ex = idx % W, ey = idx / W;                       // a wave: 64 consecutive cells of one line
+            if (ey < s || ey >= H - s) continue;                        // (uniform within the wave)
+            const int c = sC[idx];
+            const double xs = src[idx - W], xw = src[idx - 1], xc = src[idx], xe = src[idx + 1], xn = src[idx + W];
+            double o;
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != a.cmain) == 0ull))) {
+                double acc = 0.0;
+                acc = fma(m1, xs, acc);
+                acc = fma(m2, xw, acc);
+                acc = fma(m3, xc, acc);
+                acc = fma(m4, xe, acc);
+                acc = fma(m5, xn, acc);
+                o = xc + mcf * (sF[idx] - acc);
+            } else {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                double acc = 0.0;
+                acc = fma(t01.y, xs, acc);
+                acc = fma(t23.x, xw, acc);
+                acc = fma(t23.y, xc, acc);
+                acc = fma(t45.x, xe, acc);
+                acc = fma(t45.y, xn, acc);
+                o = xc + t67.y * (sF[idx] - acc);
+            }
+            const int64_t row = r00 + (int64_t)ey * a.nx + ex;
+            if (ex >= s && ex < W - s) dst[idx] = (row >= 0 && row < a.n) ? o : 0.0;
+        }
+        __syncthreads();
+    }
+
+    // ---- the inner cells that lie on the grid ----
+    const double* const res = sX + (K & 1) * CELLS;
+#pragma unroll
+    for (int i = 0; i < CELLS / NT; ++i) {
+        const int idx = tid + i * NT;
+        const int ex = idx % W, ey = idx / W;
+        const int gx = tx0 + ex, gy = ty0 + ey;
+        if (ex >= K && ex < W - K && ey >= K && ey < H - K && gx < a.nx && gy < a.nlines)
+            a.out[(int64_t)gy * a.nx + gx] = res[idx];
+    }
+}
+
+}  // namespace mgk

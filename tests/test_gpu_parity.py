@@ -958,6 +958,47 @@ def test_row_classes_fall_back_when_there_are_too_many_distinct_rows():
         assert np.array_equal(outs[0], outs[1]), case
 
 
+@pytest.mark.parametrize("c,lo,hi", [(8, 1, 4), (5, 1, 5), (3, 2, 6)])
+def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi):
+    """mg_jacobi2.hip.h, sdia_jacobik2d: up to five Jacobi sweeps per launch on 2-D levels (tile region in LDS, the
+    exact region shrinks by one ring per sweep) must reproduce single sweeps bit for bit -- for sweep counts that
+    split into different launch sizes, grids that are not a multiple of the tile, and whole V-cycles."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(c)
+    want = {}
+    for kw in (dict(fuse_2d=0), dict(), dict(fuse_2d_k=2), dict(fuse_2d_k=3), dict(fuse_2d_k=4), dict(rows_per_lane=1)):
+        tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
+        make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
+        with DeviceHierarchy.synthetic(2, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
+            for k, v in tune.items():
+                dev.set_tuning(k, v)
+            for level in range(lo + 1, hi + 1):
+                info = dev.level_info(level)
+                assert info["symmetric_diagonals"] == 3 and info["row_classes"] > 0, info
+                n = info["n_global"]
+                if (level, "v") not in want:
+                    want[level, "v"] = rng.standard_normal(n)
+                    want[level, "f"] = rng.standard_normal(n)
+                for nw in (2, 3, 5, 6, 7, 11):
+                    dev.set_vector(level, "v", want[level, "v"])
+                    dev.set_vector(level, "f", want[level, "f"])
+                    dev.smooth(level, nw)
+                    got = dev.get_vector(level, "v")
+                    if not kw:
+                        assert dev.time_kernel("jacobik", level, 1) > 0.0
+                    if kw == dict(fuse_2d=0):
+                        want[level, nw] = got
+                    else:
+                        assert np.array_equal(got, want[level, nw]), (kw, level, nw)
+            dev.set_params(50, 49, 2.0 / 3.0)
+            dev.zero_vector(hi, "v")
+            res = dev.vcycle(hi, 3, residuals=True)
+            if kw == dict(fuse_2d=0):
+                want["res"] = res
+            else:
+                assert np.all(np.abs(res - want["res"]) <= 1e-13 * want["res"]), kw
+
+
 def test_time_kernel_reports_where_the_two_sweep_pass_is_not_used():
     """`mg_time_kernel("jacobi2")` is how bench.py finds out whether the smoother pairs sweeps on a level: an error on
     levels where it does not (2-D, too small), a duration where it does."""
