@@ -51,10 +51,14 @@ enum mg_restriction {
 
 enum mg_smoother {
     MG_SMOOTH_JACOBI = 0,           /* jacobiRelaxation, multigrid.py:223-228 */
-    MG_SMOOTH_RBGS = 1              /* red-black Gauss-Seidel / SOR with factor omega (no reference;
+    MG_SMOOTH_RBGS = 1,             /* red-black Gauss-Seidel / SOR with factor omega (no reference;
                                        BASELINE.json config 5): per sweep one in-place half sweep per
                                        colour, colour = parity of the lexicographic node index.  Needs
                                        pruned grid matrices (P1 stencils are then bipartite). */
+    MG_SMOOTH_MCGS = 2              /* nine-colour Gauss-Seidel / SOR for P2 rows (BASELINE.json config 5; no
+                                       reference): the seven parity classes of the lattice's mid-points plus the
+                                       vertices split red / black; one in-place launch per colour in ascending
+                                       order.  Valid for pruned P2 and P1 grid matrices (checked per level). */
 };
 
 /* ---- life cycle ----------------------------------------------------------------

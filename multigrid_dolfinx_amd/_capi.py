@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 
 MG_VEC_V, MG_VEC_F, MG_VEC_R, MG_VEC_ERR = 0, 1, 2, 3
 MG_RESTRICT_INJECTION, MG_RESTRICT_FULL_WEIGHTING = 0, 1
-MG_SMOOTH_JACOBI, MG_SMOOTH_RBGS = 0, 1
+MG_SMOOTH_JACOBI, MG_SMOOTH_RBGS, MG_SMOOTH_MCGS = 0, 1, 2
 MG_NORM_L2, MG_NORM_MASS = 0, 1
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),

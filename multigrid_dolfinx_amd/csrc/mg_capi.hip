@@ -135,6 +135,7 @@ struct Level {
     int ntable = 0, dcode = 0;
     bool coded = false;
     bool rb_ok = false;                     // index parity is a valid red-black colouring of the matrix
+    int mc_ok = -1;                         // the nine lattice colours are a valid colouring of the matrix (-1: not checked yet)
     // symmetric diagonal storage (replaces vals + codes when the matrix is bit-for-bit symmetric)
     double* dvals = nullptr;
     bool sdia = false;
@@ -411,6 +412,7 @@ void free_level(mg_context* c, Level& L) {
     L.ncls = 0;
     L.coded = false;
     L.rb_ok = false;
+    L.mc_ok = -1;
     L.sdia = false;
     dev_free(c, L.dinv, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.perm, (size_t)L.n_global);
@@ -546,7 +548,8 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
     a.slice0 = slice0; a.nslices = slice_count; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
-    a.color = color; a.parity0 = (int)(L.row0 & 1);
+    a.color = color; a.color_kind = c->smoother == MG_SMOOTH_MCGS ? COLOR_LATTICE9 : COLOR_PARITY;
+    a.grow0 = L.row0; a.gnx = L.g.nx; a.gny = L.g.ny;
     unsigned grid = blocks_for(slice_count, WAVES_PER_BLOCK);
     // XCD strip traversal (optional): pays when a plane is much larger than a strip
     auto plan_strips = [&]() {
@@ -904,6 +907,39 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
 }
 
+// Is lattice_color(COLOR_LATTICE9) a valid Gauss-Seidel colouring of the level's matrix?  (structure of the stored
+// non-zeros, in whatever format the level has)
+int check_coloring(mg_context* c, Level& L) {
+    if (L.halo_lo || L.halo_hi) { L.mc_ok = 0; return 0; }      // P2 rows reach two planes: whole levels only
+    EllArgs a{};
+    a.vals = L.vals; a.cols = L.cols; a.codes = L.codes; a.offsets = L.offsets; a.W = L.W;
+    a.nloc = L.nloc; a.lead = L.g.lead; a.dinv = L.dinv; a.color_kind = COLOR_LATTICE9; a.grow0 = L.row0; a.gnx = L.g.nx; a.gny = L.g.ny;
+    int* d_flag = reinterpret_cast<int*>(c->partials);
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+    const dim3 grid(blocks_for(L.nloc, 256)), blk(256);
+    if (L.sdia) {
+        a.vals = L.dvals; a.mlead = L.mlead;
+        for (int t = 0; t < 8; ++t) a.up[t] = L.up[t];
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(sdia_check_coloring<1>, grid, blk, 0, c->stream, a, L.wu, d_flag); break;
+            case 2: hipLaunchKernelGGL(sdia_check_coloring<2>, grid, blk, 0, c->stream, a, L.wu, d_flag); break;
+            default: hipLaunchKernelGGL(sdia_check_coloring<4>, grid, blk, 0, c->stream, a, L.wu, d_flag); break;
+        }
+    } else {
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(ell_check_coloring<1>, grid, blk, 0, c->stream, a, L.nslices, d_flag); break;
+            case 2: hipLaunchKernelGGL(ell_check_coloring<2>, grid, blk, 0, c->stream, a, L.nslices, d_flag); break;
+            default: hipLaunchKernelGGL(ell_check_coloring<4>, grid, blk, 0, c->stream, a, L.nslices, d_flag); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    int flag = 1;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    L.mc_ok = flag ? 0 : 1;
+    return 0;
+}
+
 // K sweeps per launch on 2-D levels (mg_jacobi2.hip.h, sdia_jacobik2d): whole, undistributed five-point levels
 // with row classes whose stored diagonals are exactly {0, +1, +nx}.
 bool sweeps2d_ok(const mg_context* c, const Level& L) {
@@ -952,6 +988,21 @@ int smooth(mg_context* c, int level, int nw) {
                         " (needs a pruned grid matrix with an odd number of nodes per axis)");
         for (int s = 0; s < nw; ++s)
             for (int color = 0; color < 2; ++color) {
+                MG_TRY(launch_ell(c, L, MODE_GS, false, L.v.base, L.f.rows, L.v.rows, nullptr, nullptr, nullptr, 0, -1, color));
+                MG_TRY(exchange_halo(c, L, L.v));
+            }
+        return 0;
+    }
+    if (c->smoother == MG_SMOOTH_MCGS) {
+        // nine-colour Gauss-Seidel for P2 rows (lattice_color): one in-place launch per colour, in ascending order
+        if (L.flat) return fail("multi-colour Gauss-Seidel needs a grid level");
+        if (L.mc_ok < 0) MG_TRY(check_coloring(c, L));
+        if (!L.mc_ok)
+            return fail("the nine lattice colours are not a valid colouring of level " + std::to_string(level) +
+                        " (needs a pruned P1 / P2 grid matrix)");
+        for (int s = 0; s < nw; ++s)
+            for (int color = 0; color < 9; ++color) {
+                if (c->dim == 2 && (color & 2)) continue;            // (nx, 1, nz) storage: j is always 0
                 MG_TRY(launch_ell(c, L, MODE_GS, false, L.v.base, L.f.rows, L.v.rows, nullptr, nullptr, nullptr, 0, -1, color));
                 MG_TRY(exchange_halo(c, L, L.v));
             }
@@ -1385,6 +1436,9 @@ void drop_graphs(mg_context* c) {
 // swaps are re-applied on the host after a replay.
 int vcycle_graphed(mg_context* c, int level) {
     if (!c->direct.tried) { MG_TRY(build_direct(c)); MG_TRY(validate_direct(c)); }
+    if (c->smoother == MG_SMOOTH_MCGS)                   // (the check synchronises: not inside a capture)
+        for (int l = 1; l <= level; ++l)
+            if (c->L[l].mc_ok < 0 && !c->L[l].flat) MG_TRY(check_coloring(c, c->L[l]));
     if (!c->use_graph || c->comm.active() || level == 0 || !c->direct.ok) return vcycle(c, level);
     if (c->keep_err)
         for (int l = 1; l <= level; ++l) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].err));
@@ -1830,7 +1884,7 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
     if (!c) return fail("null handle");
     if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
     if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
-    if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS) return fail("unknown smoother");
+    if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS && smoother != MG_SMOOTH_MCGS) return fail("unknown smoother");
     const double rtol = coarse_rtol > 0 ? coarse_rtol : c->coarse_rtol;
     const int maxit = coarse_maxit > 0 ? coarse_maxit : c->coarse_maxit;
     // captured V-cycles (vcycle_graphed) are keyed on the epoch: callers such as the Python shim set the same

@@ -49,6 +49,21 @@ template <int R> struct alignas(8) DVecU { double d[R]; };
 // the colour of a row is the parity of its global lexicographic index, a valid two-colouring of
 // the pruned P1 stencils on grids with an odd number of nodes per axis.
 enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2, MODE_GS = 3 };
+enum { COLOR_PARITY = 0, COLOR_LATTICE9 = 1 };
+
+// Colour of a lexicographic lattice index.  COLOR_LATTICE9 (P2 rows, two lattice planes of reach): the seven parity
+// classes of the mid-points keep their parity bits (1..7), the vertices (all coordinates even) are split red / black
+// by (i/2 + j/2 + k/2) mod 2 into 0 and 8: no two coupled unknowns of a pruned P2 or P1 Poisson matrix share a colour
+// (checked per level before use, ell_check_coloring).  Colours are relaxed in ascending order.
+__device__ __forceinline__ int lattice_color(int kind, int64_t g, int nx, int ny) {
+    if (kind == COLOR_PARITY) return (int)(g & 1);
+    const int64_t line = g / nx;
+    const int i = (int)(g - line * nx);
+    const int j = (int)(line % ny), k = (int)(line / ny);
+    const int par = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
+    if (par) return par;
+    return (((i >> 1) + (j >> 1) + (k >> 1)) & 1) ? 8 : 0;
+}
 
 // Geometry of one level's (slab of the) grid.  2-D grids are stored as (nx, 1, nz).
 struct Grid {
@@ -131,7 +146,10 @@ struct EllArgs {
     int dcode;              // code of offset 0 (the diagonal / padding)
     // XCD strip traversal (strip_ns == 0: chunked map): see strip_block()
     int color;              // MODE_GS: colour relaxed by this launch
-    int parity0;            // MODE_GS: parity of the global index of local row 0
+    int color_kind;         // MODE_GS: 0 = parity of the global lexicographic index (red-black), 1 = the nine lattice
+                            //          colours of P2 rows (row_color)
+    int64_t grow0;          // MODE_GS: global lexicographic index of local row 0
+    int gnx, gny;           // MODE_GS: lattice points per line / lines per plane (colour kind 1)
     // symmetric-diagonal storage (sdia_apply): up[0] = 0, up[1..] = the positive offsets, ascending
     int up[8];
     int64_t mlead;          // matrix rows stored in front of row 0 (multiple of the slice height)
@@ -230,7 +248,7 @@ __device__ __forceinline__ void tile_epilogue(const EllArgs& a, int64_t row, con
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t rr = row + r;
-                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
+                if (MODE == MODE_GS && lattice_color(a.color_kind, rr + a.grow0, a.gnx, a.gny) != a.color) continue;
                 if (rr < a.nloc) {
                     double val;
                     if (MODE == MODE_SPMV) {
@@ -266,6 +284,18 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
     for (int t = threadIdx.x; t < a.ntable; t += BLOCK) s_off[t] = a.offsets[t];
     __syncthreads();
     double dot = 0.0;
+    if (MODE == MODE_GS && a.color_kind == COLOR_LATTICE9 && sl < a.nslices) {
+        // a colour fixes the parity of the line (j, k) except for the two vertex colours, which fix (even, even): a slice
+        // (64 R consecutive rows: part of one or two lines when a line is longer) none of whose lines can hold the colour
+        // is skipped before it streams its part of the matrix
+        const int64_t g0 = (a.slice0 + sl) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
+        const int64_t l0 = g0 / a.gnx, l1 = g1 / a.gnx;
+        const int want = (a.color == 8 ? 0 : a.color) >> 1;              // bits (j & 1) | (k & 1) << 1
+        bool any = false;
+        for (int64_t l = l0; l <= l1 && l < l0 + 4; ++l) any = any || ((int)((l % a.gny) & 1) | (int)(((l / a.gny) & 1) << 1)) == want;
+        if (l1 - l0 >= 4) any = true;
+        if (!any) sl = a.nslices;
+    }
     if (sl < a.nslices) {
         const int64_t slice = a.slice0 + sl;
         const int W = WT > 0 ? WT : a.W;                       // WT == 0: run-time width (wide stencils)
@@ -651,6 +681,53 @@ __global__ void ell_encode(const int* __restrict__ cols, unsigned long long* __r
     }
 }
 
+// flag[0] |= 1 when a stored off-diagonal entry couples two rows of the same colour (the colouring is then not a
+// Gauss-Seidel ordering of this matrix).  Entries below 1e-12 of the row's diagonal do not count: couplings that vanish
+// analytically (P2 vertex-vertex pairs across a face or body diagonal) come out of an assembly as round-off of that size
+// when h is not a power of two; a colour launch treats them Jacobi-style, like the oracle does.  One thread per row;
+// offset-coded or int32 columns.
+template <int R>
+__global__ void ell_check_coloring(EllArgs a, int64_t nslices, int* flag) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    constexpr int S = WAVE * R;
+    const int64_t slice = row / S, within = row % S;
+    const int mine = lattice_color(a.color_kind, row + a.grow0, a.gnx, a.gny);
+    bool bad = false;
+    for (int k = 0; k < a.W; ++k) {
+        const double v = a.vals[((size_t)slice * a.W + k) * S + within];
+        if (fabs(v * a.dinv[row]) <= 1e-12) continue;
+        int64_t off;
+        if (a.codes) {
+            const unsigned long long w = a.codes[((size_t)slice * ((a.W + 7) / 8) + k / 8) * S + within];
+            off = a.offsets[(int)((w >> (8 * (k % 8))) & 0xffull)];
+        } else {
+            off = (int64_t)a.cols[((size_t)slice * a.W + k) * S + within] - (a.lead + row);
+        }
+        if (off != 0 && lattice_color(a.color_kind, row + off + a.grow0, a.gnx, a.gny) == mine) bad = true;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// (the same for symmetric diagonal storage: the stored upper entries name every coupled pair)
+template <int R>
+__global__ void sdia_check_coloring(EllArgs a, int wu, int* flag) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    constexpr int S = WAVE * R;
+    const int64_t m = row + a.mlead;
+    const size_t base = (size_t)(m / S) * wu * S + (size_t)(m % S);
+    const double diag = a.vals[base];
+    const int mine = lattice_color(a.color_kind, row + a.grow0, a.gnx, a.gny);
+    bool bad = false;
+    for (int c = 1; c < wu; ++c) {
+        const double v = a.vals[base + (size_t)c * S];
+        if (a.up[c] == 0 || fabs(v) <= 1e-12 * fabs(diag)) continue;
+        if (lattice_color(a.color_kind, row + a.up[c] + a.grow0, a.gnx, a.gny) == mine) bad = true;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 // One wave = one slice.  MODE_RESIDUAL: out = f - A x.  MODE_JACOBI: out = x + w D^-1 (f - A x)
 // (jacobiRelaxation, multigrid.py:226, in the algebraically identical one-matrix form).
 // MODE_SPMV: out = A x, with DOT also partial sums of x . (A x).
@@ -718,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply(EllArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t rr = row + r;
-                if (MODE == MODE_GS && (int)((rr + a.parity0) & 1) != a.color) continue;
+                if (MODE == MODE_GS && lattice_color(a.color_kind, rr + a.grow0, a.gnx, a.gny) != a.color) continue;
                 if (rr < a.nloc) {
                     double val;
                     if (MODE == MODE_SPMV) {

@@ -218,7 +218,7 @@ class DeviceHierarchy:
     def set_params(self, mu1: int, mu2: int, omega: float, restriction: str = "direct",
                    coarse_rtol: float = 1e-14, coarse_maxit: int = 20000, keep_err: bool = False,
                    smoother: str = "jacobi"):
-        sm = {"jacobi": _capi.MG_SMOOTH_JACOBI, "rbgs": _capi.MG_SMOOTH_RBGS}[smoother]
+        sm = {"jacobi": _capi.MG_SMOOTH_JACOBI, "rbgs": _capi.MG_SMOOTH_RBGS, "mcgs": _capi.MG_SMOOTH_MCGS}[smoother]
         check(self._lib.mg_set_params(self._h, int(mu1), int(mu2), float(omega), _RESTRICT[restriction],
                                       sm, float(coarse_rtol), int(coarse_maxit), 1 if keep_err else 0))
 

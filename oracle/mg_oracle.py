@@ -37,7 +37,7 @@ import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.linalg import spsolve
 
-__all__ = ["get_jacobi_matrices", "jacobi_relaxation", "rbgs_relaxation", "Oracle"]
+__all__ = ["get_jacobi_matrices", "jacobi_relaxation", "rbgs_relaxation", "lattice9_colors", "Oracle"]
 
 
 def get_jacobi_matrices(A_and_level):
@@ -61,13 +61,32 @@ def jacobi_relaxation(A_jac, v, f, nw, omega):
     return v
 
 
+def lattice9_colors(grid_index, N, dim):
+    """Nine colours for P2 rows on the (N+1)^dim lattice (N even): the seven parity classes of the edge / face /
+    body mid-points (colour = parity bits of (i, j, k), 1..7) and the vertices -- all coordinates even -- split red /
+    black by (i/2 + j/2 + k/2) mod 2 into colours 0 and 8.  No two coupled unknowns of a pruned P2 (or P1) Poisson
+    matrix share a colour (tests/test_oracle_golden.py checks that on the assembled matrices).  2-D lattices use the
+    bits of (i, 0, k), matching the device's (nx, 1, nz) storage.  NO REFERENCE COUNTERPART."""
+    n1 = N + 1
+    g = np.asarray(grid_index, dtype=np.int64)
+    i = g % n1
+    if dim == 3:
+        j, k = (g // n1) % n1, g // (n1 * n1)
+    else:
+        j, k = np.zeros_like(g), g // n1
+    par = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2)
+    vertex = (((i >> 1) + (j >> 1) + (k >> 1)) & 1) * 8
+    return np.where(par == 0, vertex, par)
+
+
 def rbgs_relaxation(A, v, f, nw, omega, color):
-    """`nw` red-black Gauss-Seidel (SOR factor `omega`) sweeps: per sweep, rows of colour 0 then rows of
-    colour 1 are relaxed in place, `v_i += omega (f_i - (A v)_i) / a_ii`.  NO REFERENCE COUNTERPART
-    (BASELINE.json config 5 names the smoother; the reference only has Jacobi): parity unpinned."""
+    """`nw` multi-colour Gauss-Seidel (SOR factor `omega`) sweeps: per sweep the colours are visited in ascending
+    order and the rows of one colour are relaxed in place, `v_i += omega (f_i - (A v)_i) / a_ii` (red-black: `color`
+    in {0, 1}; P2: `lattice9_colors`).  NO REFERENCE COUNTERPART (BASELINE.json config 5 names the smoother; the
+    reference only has Jacobi): parity unpinned."""
     v = np.array(v, dtype=np.float64, copy=True)
     d_inv = 1.0 / A.diagonal()
-    rows = [np.flatnonzero(color == c) for c in (0, 1)]
+    rows = [np.flatnonzero(color == c) for c in np.unique(color)]
     parts = [A[r, :] for r in rows]
     for _ in range(nw):
         for r, Ar in zip(rows, parts):
@@ -202,7 +221,11 @@ class Oracle:
         if smoother == "jacobi":
             return jacobi_relaxation(A_h, v, f, nw, self.omega)
         level = A_h[2]
-        return rbgs_relaxation(self.A_sp_dict[level][0], v, f, nw, self.omega, self.grid_index[level] & 1)
+        if smoother == "mcgs":
+            color = lattice9_colors(self.grid_index[level], self.elements(level), self.dim)
+        else:
+            color = self.grid_index[level] & 1
+        return rbgs_relaxation(self.A_sp_dict[level][0], v, f, nw, self.omega, color)
 
     def v_cycle(self, A_h, v_h, f_h, test=False, restriction="direct", smoother="jacobi"):
         """One recursive V(mu1, mu2) cycle; follows `multigrid.py:231-268`.

@@ -732,6 +732,54 @@ def test_p2_matrices_wide_stencils_match_oracle(dim, cells, seed):
         assert rel_l2(dev.get_vector(2, "v"), exact) <= 1e-11
 
 
+@pytest.mark.parametrize("dim,cells,seed", [(2, (4, 8, 16), 6), (3, (2, 4, 8), None), (3, (4, 8, 16), 1)])
+def test_nine_colour_gauss_seidel_on_p2_matches_oracle(dim, cells, seed):
+    """BASELINE config 5: P2 rows + Gauss-Seidel (no reference implementation: parity unpinned, oracle only).  P2
+    rows couple unknowns of equal index parity, so the smoother uses nine lattice colours (`smoother="mcgs"`); red-black
+    is refused.  Sweeps and whole cycles against the oracle (33^3 lattice in the last case), the manufactured solution as
+    a fixed point, residuals falling monotonically."""
+    import types
+    from multigrid_dolfinx_amd._capi import MgError
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle, lattice9_colors, rbgs_relaxation
+    levels = {l: poisson.p2_level(N, dim, seed=seed) for l, N in enumerate(cells)}
+    c = 2 * cells[0]
+    bag = types.SimpleNamespace(
+        mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=c,
+        coarsest_level=0, finest_level=2, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+        b_dict={l: L.b for l, L in levels.items()}, mu0=2, mu1=2, mu2=2, omega=1.0,
+        residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None)
+    gi = {l: L.grid_index for l, L in levels.items()}
+    orc = Oracle(bag, gi, dim=dim)
+    f = bag.b_dict[2]
+    rng = np.random.default_rng(9)
+    v0 = rng.standard_normal(f.shape)
+    A = bag.A_sp_dict[2][0].copy()
+    A.eliminate_zeros()
+    color = lattice9_colors(gi[2], levels[2].N, dim)
+    for R in (1, 2):
+        with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi, rows_per_lane=R) as dev:
+            for omega in (1.0, 1.15):
+                dev.set_params(2, 2, omega, smoother="mcgs")
+                dev.set_vector(2, "v", v0)
+                dev.set_vector(2, "f", f)
+                dev.smooth(2, 2)
+                want = rbgs_relaxation(A, v0, f, 2, omega, color)
+                assert rel_l2(dev.get_vector(2, "v"), want) <= TOL_SWEEP
+            dev.set_params(2, 2, 1.0, smoother="mcgs")
+            want = orc.v_cycle(orc.A_jacobi_sp_dict[2], np.zeros_like(f), f, smoother="mcgs")
+            assert rel_l2(_one_cycle(dev, 2, f), want) <= TOL_ITER
+            res = dev.vcycle(2, 6, residuals=True)
+            assert np.all(res[1:] < res[:-1])
+            exact = levels[2].exact()
+            dev.set_vector(2, "v", exact)
+            dev.vcycle(2, 1)
+            assert rel_l2(dev.get_vector(2, "v"), exact) <= 1e-11
+            dev.set_params(1, 1, 1.0, smoother="rbgs")
+            with pytest.raises(MgError, match="two-colouring"):
+                dev.smooth(2, 1)
+
+
 def test_full_multigrid_with_the_reference_norms(mg, tmp_path, monkeypatch):
     """FullMultiGrid's stop test in the reference's own terms (multigrid.py:288-302): residual and error in the
     L2(Omega) norm, here through the P1 mass matrix handed over in the `V_fine_dolfx` slot."""

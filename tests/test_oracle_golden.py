@@ -182,3 +182,36 @@ def test_rbgs_oracle_against_plain_loops():
                     v[i, 0] += 1.15 * (L.b[i, 0] - A[i] @ v[:, 0]) / A[i, i]
         assert np.abs(got - v).max() <= 1e-13
         assert np.array_equal(v0, v0)
+
+
+def test_nine_colour_gauss_seidel_oracle_against_plain_loops():
+    """BASELINE config 5's smoother on P2 rows (no reference: parity unpinned).  The nine lattice colours must be a
+    proper colouring of the pruned P2 matrices (2-D and 3-D, lexicographic and permuted numbering), and the
+    vectorised oracle must equal a scalar Gauss-Seidel loop that visits the rows colour by colour."""
+    from multigrid_dolfinx_amd import poisson
+    from oracle.mg_oracle import lattice9_colors, rbgs_relaxation
+    for dim, N, seed in ((2, 4, None), (2, 3, 1), (3, 2, None), (3, 3, 2)):
+        L = poisson.p2_level(N, dim, seed=seed)
+        A = L.A.copy()
+        A.eliminate_zeros()
+        color = lattice9_colors(L.grid_index, L.N, dim)
+        assert set(np.unique(color)) <= set(range(9)) and len(np.unique(color)) == (5 if dim == 2 else 9)
+        D = A.toarray()
+        rng = np.random.default_rng(0)
+        v0 = rng.standard_normal((L.n, 1))
+        got = rbgs_relaxation(A, v0, L.b, 2, 1.1, color)
+        v = v0.copy()
+        for _ in range(2):
+            for c in np.unique(color):
+                for i in np.flatnonzero(color == c):
+                    # a proper colouring (but for round-off couplings of 1e-18 a_ii where h is not a power of two)
+                    assert all(color[j] != c for j in np.flatnonzero(np.abs(D[i]) > 1e-12 * D[i, i]) if j != i)
+                    v[i, 0] += 1.1 * (L.b[i, 0] - D[i] @ v[:, 0]) / D[i, i]
+        assert np.abs(got - v).max() <= 1e-12 * max(1.0, np.abs(v).max())
+    # the same colours are proper for the pruned P1 seven-point rows as well
+    for dim, N in ((2, 6), (3, 4)):
+        L = poisson.make_level(N, dim, seed=2, keep_zeros=False)
+        color = lattice9_colors(L.grid_index, N, dim)
+        C = L.A.tocoo()
+        off = C.row != C.col
+        assert not np.any(color[C.row[off]] == color[C.col[off]])
