@@ -34,6 +34,9 @@ CONFIGS = {
     "c2": (2, 4, 8, "2D Poisson P1, 5-level 2048x2048 fine grid"),
     "c3": (3, 2, 5, "3D Poisson P1, 4-level 256^3 fine grid"),
     "c4": (3, 2, 7, "3D Poisson P1, 6-level 1024^3 fine grid"),
+    # BASELINE.json config 5 (no reference counterpart: the reference is P1 / Jacobi only): P2 elements on the
+    # 513^3-point lattice (256 cells per dimension), nine-colour Gauss-Seidel, V(2,2) unless --mu says otherwise
+    "c5": (3, 2, 6, "3D Poisson P2, 5-level 513^3-point lattice (512^3 steps), nine-colour Gauss-Seidel"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -64,8 +67,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
-    ap.add_argument("--mu", type=int, default=50, help="pre- and post-smoothing sweeps (reference: 50)")
-    ap.add_argument("--omega", type=float, default=2.0 / 3.0)
+    ap.add_argument("--mu", type=int, default=None, help="pre- and post-smoothing sweeps (default: the reference's 50; "
+                                                         "2 for the Gauss-Seidel configuration c5)")
+    ap.add_argument("--omega", type=float, default=None, help="default 2/3 (Jacobi), 1 (Gauss-Seidel)")
     ap.add_argument("--rows-per-lane", type=int, default=None)
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--offset-codes", type=int, default=None, help="0 = int32 column indices")
@@ -249,6 +253,11 @@ def build_hierarchy(args, rv):
     if args.transport == "gloo":            # ranks may share a GPU in this debugging mode
         import torch
         device = rv.local_rank % max(1, torch.cuda.device_count())
+    if args.config == "c5":
+        if rv.world > 1:
+            raise SystemExit("config c5 (P2 rows reach two lattice planes) is single-GPU for now: the slab halo is one plane")
+        return DeviceHierarchy.synthetic_p2(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega, device=device,
+                                            **tuning)
     return DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega,
                                      prune_zeros=True, device=device, comm=comm, **tuning)
 
@@ -273,15 +282,25 @@ def cpu_baseline(args):
     from multigrid_dolfinx_amd import poisson
     from oracle.mg_oracle import Oracle
     dim, lo, hi, _ = CONFIGS[args.config]
-    s_hi = min(hi, args.cpu_sample_level if dim == 3 else 7)     # same coarsest grid, fewer fine levels
+    p2 = args.config == "c5"
+    s_hi = min(hi, (3 if p2 else args.cpu_sample_level) if dim == 3 else 7)     # same coarsest grid, fewer fine levels
     s_lo = min(lo, s_hi - 1)
-    bag = poisson.make_hierarchy(dim, s_lo, s_hi, c=8, mu0=1, mu1=args.mu, mu2=args.mu, omega=args.omega)
+    if p2:
+        import types
+        levels = {l: poisson.p2_level(4 * 2 ** l, dim) for l in range(s_lo, s_hi + 1)}
+        bag = types.SimpleNamespace(
+            mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=8,
+            coarsest_level=s_lo, finest_level=s_hi, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+            b_dict={l: L.b for l, L in levels.items()}, mu0=1, mu1=args.mu, mu2=args.mu, omega=args.omega,
+            residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None, levels=levels)
+    else:
+        bag = poisson.make_hierarchy(dim, s_lo, s_hi, c=8, mu0=1, mu1=args.mu, mu2=args.mu, omega=args.omega)
     orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=dim)
     f = bag.b_dict[s_hi]
     v = np.zeros_like(f)
     cycles, t0 = 0, time.perf_counter()
     while cycles < 1 or (time.perf_counter() - t0 < 10.0 and cycles < 20):
-        v = orc.v_cycle(orc.A_jacobi_sp_dict[s_hi], v, f)
+        v = orc.v_cycle(orc.A_jacobi_sp_dict[s_hi], v, f, smoother="mcgs" if p2 else "jacobi")
         cycles += 1
     dt = time.perf_counter() - t0
     n_s = bag.levels[s_hi].n
@@ -299,6 +318,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    p2 = args.config == "c5"
+    if args.mu is None:
+        args.mu = 2 if p2 else 50
+    if args.omega is None:
+        args.omega = 1.0 if p2 else 2.0 / 3.0
     # Contract: ONE JSON line on stdout.  RCCL (version banner at communicator set-up), gloo and the HIP
     # runtime write to the C-level stdout at times, so file descriptor 1 points at stderr for the whole run and
     # the JSON line goes to the real stdout at the very end.
@@ -320,6 +344,7 @@ def main():
     info = h.level_info(hi)
     jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
     res_ms = h.time_kernel("residual", hi, args.kernel_reps)
+    gs_ms = h.time_kernel("gs", hi, max(2, args.kernel_reps // 4)) if p2 else None
     try:        # the smoother pairs sweeps on this level (mg_jacobi2.hip.h): that launch is the dominant one
         pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
     except Exception:
@@ -350,7 +375,7 @@ def main():
         return 12 * W + 32
 
     sweeps_per_launch = (multi_k or 2) if pair_ms else 1
-    dom_ms = pair_ms if pair_ms else jac_ms
+    dom_ms = pair_ms if pair_ms else (gs_ms if gs_ms else jac_ms)
     dom_classes = classes_in_pair if pair_ms else classes_in_sweep
     fmt_row = format_bytes_per_row(dom_classes)
     bytes_launch = fmt_row * n_loc
@@ -358,7 +383,9 @@ def main():
     # SURVEY.md 8(d)'s CSR byte model of the same work, for comparison only (never a roofline fraction: the shipped
     # formats do not move these bytes)
     csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
-    if multi_k:
+    if gs_ms:
+        kernel_id = "ell_apply_coded<0, 2, MODE_GS> x 9 colours"
+    elif multi_k:
         kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
     elif pair_ms:
         kernel_id = ("sdia_jacobi2c_finest<12, 2>" if dom_classes else "sdia_jacobi2_finest<2, 8, 2, false>")
@@ -402,7 +429,7 @@ def main():
             h.set_tuning("class_sweeps", 1)
 
     # conventional V(2,2) for information
-    h.set_params(2, 2, args.omega)
+    h.set_params(2, 2, args.omega, smoother="mcgs" if p2 else "jacobi")
     v22 = timed_cycles(h, rv, hi, 1, max(2, args.steps))
     v22_per_s = max(2, args.steps) / v22
     mem = h.memory_bytes()
@@ -417,7 +444,10 @@ def main():
             "value": per_s, "unit": "V-cycles/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "
+            "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) omega={args.omega:.4f}, "
+                                   f"injection, Q1 prolongation on the lattice, PCG coarsest solve, up to 51 entries per row; "
+                                   f"no reference implementation exists for this configuration (parity unpinned)" if p2 else
+                                   f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "
                                    f"omega={args.omega:.4f}, injection, Q1 prolongation, exact block-LU coarsest solve, "
                                    f"explicit zeros pruned (7-point rows)" if dim == 3 else
                                    f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi",
@@ -426,7 +456,9 @@ def main():
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": kernel_id + (f" ({sweeps_per_launch} fine-level weighted-Jacobi sweeps per launch" if pair_ms else
+                         "kernel": kernel_id + (" (one fine-level Gauss-Seidel sweep = nine colour launches; kernel_ms is their sum"
+                                                if gs_ms else
+                                                f" ({sweeps_per_launch} fine-level weighted-Jacobi sweeps per launch" if pair_ms else
                                                 " (one fine-level weighted-Jacobi sweep per launch") +
                                    (", class-coded rows)" if dom_classes else ")"),
                          "bytes_model": (f"{fmt_row} B per row and launch = what the shipped format must stream: "

@@ -127,6 +127,15 @@ int mg_set_level_grid(mg_handle h, int level, int elements_per_dim, int64_t n_ro
  * (lexicographic numbering), without a host CSR -- the only way to set up 1025^3
  * unknowns.  Also fills MG_VEC_F with the lifted right-hand side. */
 int mg_gen_poisson_level(mg_handle h, int level, int elements_per_dim, int prune_zeros);
+/* The same for elements whose unknowns fill a lattice with one row per parity class of the lattice point -- P2 on the
+ * structured simplicial mesh, BASELINE.json config 5 (no reference counterpart: the reference is P1 only).  The
+ * caller hands over, for each of the eight classes (i & 1) | (j & 1) << 1 | (k & 1) << 2, the interior stencil as
+ * count[class] (offset, value) pairs -- offsets[class][t][3] = (di, dj, dk) in ascending column order, at most
+ * 64 per class, values[class][t] for this level's mesh width -- and the load of the constant source; the device writes
+ * the tiles with the reference's boundary treatment (identity rows, zeroed columns, lifted right-hand side,
+ * Multigrid_prototype.py:77-108).  `lattice_steps` = lattice points per dimension - 1 (even).  Single GPU. */
+int mg_gen_lattice_level(mg_handle h, int level, int lattice_steps, int width, const int* count, const int* offsets,
+                         const double* values, const double* load);
 /* getJacobiMatrices (multigrid.py:48-56) as a stand-alone set-up kernel, for callers that
  * want the reference's split operands back: for every stored entry a_ij of the CSR matrix
  * writes scaled[q] = a_ij / a_ii computed as (1/a_ii) * a_ij, keep[q] = 1 unless the entry
@@ -259,7 +268,8 @@ int mg_counters(mg_handle h, int64_t* uploads, int64_t* downloads, int64_t* grap
  * one kernel of the path on `level`, measured with HIP events on the handle's own
  * stream ("jacobi", "residual", "restrict", "prolong", "norm2"; "jacobi2" = the two-sweep pass, an
  * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies;
- * "jacobik" = one launch of the K-sweep 2-D kernel with K = "fuse_2d_k", an error on levels that do not use it).
+ * "jacobik" = one launch of the K-sweep 2-D kernel with K = "fuse_2d_k", an error on levels that do not use it;
+ * "gs" = one full Gauss-Seidel sweep, all colours, with the configured Gauss-Seidel smoother).
  * Used by bench.py for the roofline figure.  mg_sync waits for the handle's stream. */
 int mg_time_kernel(mg_handle h, const char* kernel, int level, int reps, double* avg_ms);
 int mg_sync(mg_handle h);

@@ -43,6 +43,7 @@ SIGNATURES = {
                          C.c_void_p, C.c_int],
     "mg_set_level_grid": [_H, C.c_int, C.c_int, C.c_int64, C.c_void_p],
     "mg_gen_poisson_level": [_H, C.c_int, C.c_int, C.c_int],
+    "mg_gen_lattice_level": [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mg_jacobi_split": [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_void_p],
     "mg_set_params": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int],

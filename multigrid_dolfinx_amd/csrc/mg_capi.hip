@@ -2156,6 +2156,60 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     return 0;
 }
 
+int mg_gen_lattice_level(mg_handle c, int level, int N, int width, const int* count, const int* offsets, const double* values,
+                         const double* load) {
+    MG_TRY(check_level(c, level, false));
+    if (N <= 0 || (N & 1)) return fail("lattice levels need an even, positive number of lattice steps per dimension");
+    if (!count || !offsets || !values || !load) return fail("null stencil tables");
+    if (width < 1 || width > LAT_MAX) return fail("stencil width out of range");
+    if (c->comm.active()) return fail("lattice levels (two planes of reach) are single-GPU only");
+    for (int p = 0; p < 8; ++p)
+        if (count[p] < 0 || count[p] > width) return fail("a class has more entries than the stated width");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, L, level, N));
+    DevTemp d_count, d_off, d_val, d_load;
+    MG_TRY(d_count.alloc(8 * sizeof(int)));
+    MG_TRY(d_off.alloc((size_t)8 * LAT_MAX * 3 * sizeof(int)));
+    MG_TRY(d_val.alloc((size_t)8 * LAT_MAX * sizeof(double)));
+    MG_TRY(d_load.alloc(8 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_count.p, count, 8 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off.p, offsets, (size_t)8 * LAT_MAX * 3 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_val.p, values, (size_t)8 * LAT_MAX * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_load.p, load, 8 * sizeof(double), hipMemcpyHostToDevice));
+    LatticeArgs a{};
+    a.g = L.g; a.N = N; a.dim = c->dim; a.W = width;
+    a.count = static_cast<const int*>(d_count.p); a.off = static_cast<const int*>(d_off.p);
+    a.val = static_cast<const double*>(d_val.p); a.load = static_cast<const double*>(d_load.p);
+    L.W = width;
+    MG_TRY(alloc_ell(c, L));
+    MG_TRY(alloc_level_vectors(c, L));
+    unsigned long long* d_counts = reinterpret_cast<unsigned long long*>(c->partials);
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), c->stream));
+    const dim3 grid = grid3(L.g, L.g.nk), blk(kPlaneBlock);
+    switch (L.R) {
+        case 1: hipLaunchKernelGGL(gen_lattice<1>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+        case 2: hipLaunchKernelGGL(gen_lattice<2>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+        default: hipLaunchKernelGGL(gen_lattice<4>, grid, blk, 0, c->stream, a, L.vals, L.cols, L.dinv, L.f.rows, d_counts); break;
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long counts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    L.nnz_stored = counts[0];
+    L.nnz_nonzero = counts[1];
+    MG_TRY(encode_level(c, L));
+    MG_TRY(repack_sdia(c, L, level));
+    if (level + 1 < c->nlev) {
+        MG_TRY(vec_alloc(c, L, &L.ftrue));
+        HIP_TRY(hipMemcpyAsync(L.ftrue.base, L.f.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    L.set = true;
+    L.has_matrix = true;
+    return 0;
+}
+
 int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr, int indptr_is_64,
                     const int32_t* indices, const double* data, double* dinv, double* scaled, unsigned char* keep) {
     if (!indptr || !indices || !data || !dinv || !scaled || !keep) return fail("null argument");
@@ -2606,6 +2660,10 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
         if (k == "jacobik") {
             if (!sweeps2d_ok(c, L)) return fail("level does not use the K-sweep 2-D kernel");
             return launch_jacobik(c, L, c->fuse_2d_k, L.v.rows, L.f.rows, L.v2.rows);
+        }
+        if (k == "gs") {            // one full Gauss-Seidel sweep (all colours) with the configured colouring
+            if (c->smoother == MG_SMOOTH_JACOBI) return fail("the configured smoother is Jacobi");
+            return smooth(c, level, 1);
         }
         if (k == "residual") return residual(c, level);
         if (k == "restrict") return level > 0 ? restrict_to(c, level, c->restriction) : fail("level 0");

@@ -1006,6 +1006,70 @@ __global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, do
     }
 }
 
+// ---- synthetic level from per-parity-class lattice stencils (P2 elements, BASELINE config 5) ---------------------
+// On the structured simplicial mesh every interior lattice node of one parity class (i, j, k mod 2) has the same row:
+// the caller hands over the eight interior stencils (offsets in ascending column order + values for this level's h)
+// and the load of a constant source per class; the kernel applies the reference's boundary treatment
+// (Multigrid_prototype.py:77-108: identity rows, zeroed columns, lifted right-hand side) exactly as gen_poisson does.
+constexpr int LAT_MAX = 64;
+struct LatticeArgs {
+    Grid g;
+    int N, dim, W;
+    const int* count;           // [8]
+    const int* off;             // [8][LAT_MAX][3]  (di, dj, dk), ascending column order
+    const double* val;          // [8][LAT_MAX]
+    const double* load;         // [8]
+};
+
+template <int R>
+__global__ void gen_lattice(LatticeArgs a, double* vals, int* cols, double* dinv, double* f, unsigned long long* counts) {
+    int i = 0, j = 0;
+    const bool active = plane_node(a.g, &i, &j);
+    const int kl = blockIdx.y;
+    unsigned nz = 0, kept = 0;
+    if (active) {
+        const int k = a.g.k0 + kl;
+        const int64_t lr = (int64_t)kl * a.g.plane + (int64_t)j * a.g.nx + i;
+        const size_t base = (size_t)(lr / (WAVE * R)) * a.W * (WAVE * R) + (size_t)(lr % (WAVE * R));
+        GenArgs ga{};                       // boundary data / boundary test shared with gen_poisson
+        ga.g = a.g; ga.N = a.N; ga.dim = a.dim;
+        const bool bnd = gen_on_boundary(ga, i, j, k);
+        const int cls = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
+        double b = bnd ? gen_g(ga, i, j, k) : a.load[cls];
+        double diag = 1.0;
+        if (bnd) {
+            vals[base] = 1.0;
+            cols[base] = (int)(a.g.lead + lr);
+            kept = nz = 1;
+        } else {
+            const int n = a.count[cls];
+            for (int t = 0; t < n; ++t) {
+                const int* o = a.off + ((size_t)cls * LAT_MAX + t) * 3;
+                const int ii = i + o[0], jj = j + o[1], kk = k + o[2];
+                double v = a.val[(size_t)cls * LAT_MAX + t];
+                if (gen_on_boundary(ga, ii, jj, kk)) {
+                    b = b - v * gen_g(ga, ii, jj, kk);
+                    continue;                               // zeroed column, pruned
+                }
+                if (o[0] == 0 && o[1] == 0 && o[2] == 0) diag = v;
+                if ((int)kept < a.W) {
+                    vals[base + (size_t)kept * (WAVE * R)] = v;
+                    cols[base + (size_t)kept * (WAVE * R)] = (int)(a.g.lead + lr + (int64_t)o[2] * a.g.plane + (int64_t)o[1] * a.g.nx + o[0]);
+                }
+                ++kept; ++nz;
+            }
+        }
+        dinv[lr] = 1.0 / diag;
+        f[lr] = b;
+    }
+    const unsigned ksum = (unsigned)wave_sum((double)kept);
+    const unsigned zsum = (unsigned)wave_sum((double)nz);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)ksum);
+        atomicAdd(&counts[1], (unsigned long long)zsum);
+    }
+}
+
 // ---- grid transfers (lexicographic index arithmetic; no coordinate hashing) ---------------------
 // Injection (Restriction2D_direct, multigrid.py:123-132): coarse (I,J,K) <- fine (2I,2J,2K).
 __global__ void restrict_inject(Grid gc, Grid gf, const double* __restrict__ rf, double* __restrict__ fc) {

@@ -215,6 +215,32 @@ class DeviceHierarchy:
         check(self._lib.mg_gen_poisson_level(self._h, self._idx(level), self.elements(level),
                                              1 if prune_zeros else 0))
 
+    def gen_p2_level(self, level: int):
+        """Device-side synthetic P2 level on the lattice with `elements(level)` steps per dimension (= twice the
+        cells; BASELINE config 5), from the per-class interior stencils of `poisson.p2_stencils`."""
+        from .poisson import p2_stencils
+        if not hasattr(self, "_p2_tables"):
+            self._p2_tables = p2_stencils(self.dim)
+        count, offsets, values, load = self._p2_tables
+        steps = self.elements(level)
+        h = 2.0 / steps                                 # cell size
+        vals = np.ascontiguousarray(values * h ** (self.dim - 2))
+        ld = np.ascontiguousarray(load * h ** self.dim)
+        cnt = np.ascontiguousarray(count, dtype=np.int32)
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        check(self._lib.mg_gen_lattice_level(self._h, self._idx(level), steps, int(cnt.max()), ptr(cnt), ptr(off),
+                                             ptr(vals), ptr(ld)))
+
+    @classmethod
+    def synthetic_p2(cls, dim: int, coarsest_level: int, finest_level: int, c: int = 8, mu1: int = 2, mu2: int = 2,
+                     omega: float = 1.0, smoother: str = "mcgs", device: int = 0, **tuning):
+        """Whole P2 hierarchy from the device generator (lattices of c * 2^level steps per dimension)."""
+        h = cls(dim, coarsest_level, finest_level, c=c, device=device, **tuning)
+        for level in range(coarsest_level, finest_level + 1):
+            h.gen_p2_level(level)
+        h.set_params(mu1, mu2, omega, smoother=smoother)
+        return h
+
     def set_params(self, mu1: int, mu2: int, omega: float, restriction: str = "direct",
                    coarse_rtol: float = 1e-14, coarse_maxit: int = 20000, keep_err: bool = False,
                    smoother: str = "jacobi"):

@@ -350,3 +350,44 @@ def p2_level(N: int, dim: int, seed: Optional[int] = None) -> Level:
         return lvl
     rng = np.random.default_rng(seed + 7919 * N)
     return renumber(lvl, rng.permutation(n))
+
+
+def p2_stencils(dim: int):
+    """Interior rows of the P2 Poisson matrix per parity class of the lattice point, for mesh width h = 1 (cell
+    size; lattice spacing 1/2): `(count[8], offsets[8, 64, 3], values[8, 64], load[8])` as `mg_gen_lattice_level` takes
+    them, read off a small assembled level (`p2_level(4, dim)`, whose centre rows touch no boundary).  Values scale
+    with h^(dim-2), the load with h^dim; for h a power of two both scalings are exact, so a level generated from these
+    tables equals the assembled one bit for bit in its matrix."""
+    N = 4
+    L = p2_level(N, dim)
+    M, n1 = L.N, L.N + 1
+    h = 1.0 / N
+    A = L.A.tocsr()
+    count = np.zeros(8, dtype=np.int32)
+    offsets = np.zeros((8, 64, 3), dtype=np.int32)
+    values = np.zeros((8, 64))
+    load = np.zeros(8)
+    for cls in range(8):
+        bits = (cls & 1, (cls >> 1) & 1, (cls >> 2) & 1)
+        if dim == 2 and bits[1]:
+            continue                                   # 2-D lattices are stored as (nx, 1, nz): j is always 0
+        ijk = [4 + b for b in bits]                    # a centre node of this class
+        if dim == 2:
+            node = ijk[0] + n1 * ijk[2]
+        else:
+            node = ijk[0] + n1 * (ijk[1] + n1 * ijk[2])
+        lo, hi = A.indptr[node], A.indptr[node + 1]
+        cols, vals = A.indices[lo:hi], A.data[lo:hi]
+        keep = vals != 0.0
+        cols, vals = cols[keep], vals[keep]
+        order = np.argsort(cols)
+        cols, vals = cols[order], vals[order]
+        count[cls] = cols.size
+        for t, (cc, vv) in enumerate(zip(cols, vals)):
+            ci = cc % n1
+            cj = (cc // n1) % n1 if dim == 3 else 0
+            ck = cc // (n1 * n1) if dim == 3 else cc // n1
+            offsets[cls, t] = (ci - ijk[0], cj - ijk[1] if dim == 3 else 0, ck - ijk[2])
+            values[cls, t] = vv / h ** (dim - 2)
+        load[cls] = L.b[node, 0] / h ** dim
+    return count, offsets, values, load

@@ -780,6 +780,78 @@ def test_nine_colour_gauss_seidel_on_p2_matches_oracle(dim, cells, seed):
                 dev.smooth(2, 1)
 
 
+@pytest.mark.parametrize("dim,c,lo,hi", [(2, 4, 0, 3), (3, 4, 0, 2)])
+def test_device_p2_generator_equals_the_assembled_levels(dim, c, lo, hi):
+    """`mg_gen_lattice_level` writes P2 levels from the eight per-class interior stencils (no host matrix: the only way
+    to set up the 513^3-point lattice of BASELINE config 5).  It must be the matrix `poisson.p2_level` assembles: the
+    same residuals and sweeps on random vectors (to round-off: the assembly sums element contributions in its own
+    order), the same right-hand side, the same cycles."""
+    import types
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    levels = {l: poisson.p2_level(c * 2 ** l // 2, dim) for l in range(lo, hi + 1)}
+    bag = types.SimpleNamespace(
+        mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=c,
+        coarsest_level=lo, finest_level=hi, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+        b_dict={l: L.b for l, L in levels.items()}, mu0=2, mu1=2, mu2=2, omega=1.0,
+        residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None)
+    gi = {l: L.grid_index for l, L in levels.items()}
+    rng = np.random.default_rng(12)
+    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi) as a, \
+            DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=2, mu2=2, omega=1.0) as b:
+        for l in range(lo, hi + 1):
+            ia, ib = a.level_info(l), b.level_info(l)
+            assert ia["n_global"] == ib["n_global"] and ia["nnz_nonzero"] == ib["nnz_nonzero"]
+            fb = b.get_vector(l, "f")
+            assert np.abs(fb - bag.b_dict[l]).max() <= 1e-13 * np.abs(bag.b_dict[l]).max()
+            if l == lo:
+                continue
+            v = rng.standard_normal(fb.shape)
+            for dev in (a, b):
+                dev.set_params(2, 2, 2.0 / 3.0, smoother="jacobi")
+                dev.set_vector(l, "v", v)
+                dev.set_vector(l, "f", bag.b_dict[l])
+            a.residual(l); b.residual(l)
+            assert rel_l2(b.get_vector(l, "r"), a.get_vector(l, "r")) <= 1e-14, l
+            a.smooth(l, 2); b.smooth(l, 2)
+            assert rel_l2(b.get_vector(l, "v"), a.get_vector(l, "v")) <= 1e-14, l
+        for dev in (a, b):
+            dev.set_params(2, 2, 1.0, smoother="mcgs")
+            dev.set_vector(hi, "f", bag.b_dict[hi])
+            dev.zero_vector(hi, "v")
+        ra, rb = a.vcycle(hi, 3, residuals=True), b.vcycle(hi, 3, residuals=True)
+        assert np.all(np.abs(ra - rb) <= 1e-12 * ra)
+        assert rb[-1] < rb[0]
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at its full size on one GPU (P2 on the 513^3-point lattice, 135 M unknowns, nine-colour
+    Gauss-Seidel; no reference and no oracle at this size): properties that do not depend on the size -- the quadratic
+    manufactured solution is reproduced by P2 (zero residual, fixed point of a cycle), residual norms fall monotonically
+    from a zero guess, a Gauss-Seidel sweep is deterministic."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    with DeviceHierarchy.synthetic_p2(3, 2, 6, c=8, mu1=2, mu2=2, omega=1.0) as dev:
+        info = dev.level_info(6)
+        n1 = 513
+        assert info["n_global"] == n1 ** 3 and info["ell_width"] == 51
+        t = np.arange(n1, dtype=np.float64) / (n1 - 1)
+        exact = (1.0 + t[None, None, :] ** 2 + 2.0 * t[None, :, None] ** 2 + 3.0 * t[:, None, None] ** 2).reshape(-1, 1)
+        f_norm = dev.norm2(6, "f")
+        dev.set_vector(6, "v", exact)
+        dev.residual(6)
+        assert dev.norm2(6, "r") <= 1e-10 * f_norm
+        dev.vcycle(6, 1)
+        got = dev.get_vector(6, "v")
+        assert rel_l2(got, exact) <= 1e-11
+        del got, exact
+        dev.zero_vector(6, "v")
+        res = dev.vcycle(6, 4, residuals=True)
+        assert np.all(res[1:] < res[:-1]) and res[-1] < 0.5 * res[0], res
+        a = dev.get_vector(6, "v")
+        dev.zero_vector(6, "v")
+        dev.vcycle(6, 4)
+        assert np.array_equal(a, dev.get_vector(6, "v"))
+
+
 def test_full_multigrid_with_the_reference_norms(mg, tmp_path, monkeypatch):
     """FullMultiGrid's stop test in the reference's own terms (multigrid.py:288-302): residual and error in the
     L2(Omega) norm, here through the P1 mass matrix handed over in the `V_fine_dolfx` slot."""
