@@ -1,8 +1,12 @@
 #!/bin/bash
 # Reproduces the rocprofv3 passes summarised under profiles/ (run on the GPU box, e.g. through gpurun):
 #     bash tools/profile_round.sh r02
-# kernel trace + stats of the default bench run, then separate PMC passes (FETCH_SIZE, WRITE_SIZE, L2) of a
-# short run.  rocprofv3 must launch python3 itself (no env/bash wrapper between it and the program).
+# 1. kernel trace + stats of the default bench run (the headline workload),
+# 2. separate PMC passes (FETCH_SIZE, WRITE_SIZE, L2 hit/miss) of a short bench run -- counters never share a run
+#    with --stats or another trace domain --,
+# 3. SQ wait / busy counters of the pair pass alone (tools/pmc_jacobi2.py),
+# each condensed with profiles/summarize.py into gpurun_out/${TAG}_*.csv (copy those into profiles/).
+# rocprofv3 must launch python3 itself (no env/bash wrapper between it and the program).
 set -e
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -10,12 +14,21 @@ export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_c4_trace" -- python3 "$R/bench.py" \
-    > "$OUT/${TAG}_c4_bench.json" 2> "$OUT/${TAG}_c4_bench.err"
+echo "trace"; rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_c4_trace" -- python3 "$R/bench.py" \
+    > "$OUT/${TAG}_c4_bench_under_rocprof.json" 2> "$OUT/${TAG}_c4_bench.err"
+python3 "$R/profiles/summarize.py" trace "$OUT/${TAG}_c4_trace" "$OUT/${TAG}_c4_kernel_by_grid.csv"
+cp "$(ls "$OUT/${TAG}_c4_trace"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_c4_kernel_stats.csv"
 SHORT="--steps 1 --warmup 0 --mu 1 --kernel-reps 2 --no-cpu-baseline"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_fetch" -- python3 "$R/bench.py" $SHORT > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_write" -- python3 "$R/bench.py" $SHORT > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_l2" -- python3 "$R/bench.py" $SHORT > /dev/null 2>&1
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  N=$(echo $C | cut -d' ' -f1 | tr 'A-Z' 'a-z' | sed 's/_size//; s/tcc_hit_sum/l2/')
+  echo "pmc $N"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_$N.d" -- python3 "$R/bench.py" $SHORT > /dev/null 2> "$OUT/${TAG}_c4_pmc_$N.err"
+  python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_$N.d" "$OUT/${TAG}_c4_pmc_$N.csv"
+done
+echo "sq"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq.d" -- python3 "$R/tools/pmc_jacobi2.py" > "$OUT/${TAG}_c4_pmc_sq.log" 2>&1
+python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq.d" "$OUT/${TAG}_c4_pmc_sq.csv"
 cd "$R"
-python3 bench.py > "$OUT/${TAG}_c4_bench_plain.json" 2> "$OUT/${TAG}_c4_plain.err"
-echo "done: summarise with  python profiles/summarize.py trace|pmc gpurun_out/${TAG}_c4_... profiles/${TAG}_..."
+echo "plain"; python3 bench.py > "$OUT/${TAG}_c4_bench_untraced.json" 2> "$OUT/${TAG}_c4_untraced.err"
+rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d
+echo "done"
