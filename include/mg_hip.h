@@ -179,6 +179,10 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "fuse_even"          1 = the tile columns of the class-coded pass are equally wide, as narrow as covers the grid;
  *                          0 = always 124 cells, the last column nearly empty (0: measured faster); bit-identical
  *     "fuse_wi"            experiments: that width given directly (0 = chosen per level as above)
+ *     "march_sweeps"       the one-sweep class kernels (residual, single Jacobi sweeps, Gauss-Seidel colours) run as a
+ *                          plane march with x in LDS on whole 3-D seven-point levels (1); bit-identical either way
+ *     "march_min_rows"     ... only on levels with at least this many rows (4194304)
+ *     "march_shape"        ... 0 = 12 waves x 2 grid lines per workgroup, 1 = 16 x 2 (0)
  *     "fuse_2d"            up to "fuse_2d_k" Jacobi sweeps per launch on 2-D five-point levels with row classes (1);
  *                          bit-identical to single sweeps
  *     "fuse_2d_k"          ... at most this many per launch, 2..5 (5)

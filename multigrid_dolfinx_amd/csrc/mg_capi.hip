@@ -232,6 +232,9 @@ struct mg_context {
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     int fuse_wi = 0;                // experiments: cells per tile line with a second sweep (0: chosen per level)
     int fuse_even = 0;              // all tile columns of the class-coded pass equally wide (measured slower: more full tiles, same bytes)
+    int march_sweeps = 1;           // one-sweep class kernels as a plane march on large 3-D levels (sdia_sweep1c)
+    int64_t march_min_rows = (int64_t)1 << 22;
+    int march_shape = 0;            // 0 = 12 waves x 2 lines, 1 = 16 waves x 2 lines
     int fuse_2d = 1;                // K sweeps per launch on 2-D levels with row classes (sdia_jacobik2d)
     int fuse_2d_k = 5;              // ... at most this many (2..5)
     int fuse_xcd_chunk = 32;        // consecutive tiles of that pass per XCD at a time
@@ -537,12 +540,19 @@ void launch_ell_r(int W, int mode, bool dot, const EllArgs& a, unsigned grid, hi
     }
 }
 
+int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows, const double* f_rows, double* out_rows,
+                   int color);
+bool sweep1c_ok(const mg_context* c, const Level& L);
+
 // out = op(A, x) over all owned slices of the level
 int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
                double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr,
                int64_t slice0 = 0, int64_t slice_count = -1, int color = 0) {
     if (slice_count < 0) slice_count = L.nslices - slice0;
     if (slice_count == 0) return 0;
+    // whole large 3-D levels with row classes: one sweep as a plane march (mg_jacobi2.hip.h, sdia_sweep1c)
+    if (!dot && !done && mode != MODE_SPMV && slice0 == 0 && slice_count == L.nslices && sweep1c_ok(c, L))
+        return launch_sweep1c(c, L, mode, x_base + L.g.lead, f_rows, out_rows, color);
     EllArgs a{};
     a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
@@ -976,6 +986,59 @@ int launch_jacobik(mg_context* c, const Level& L, int K, const double* x_rows, c
         case 5: return launch_jacobik_t<5>(c, a);
         default: return fail("sweeps per launch must be in 2..5");
     }
+}
+
+// One sweep as a plane march (sdia_sweep1c): whole, undistributed 3-D seven-point levels with row classes, large enough
+// for the march to pay ("march_min_rows").
+bool sweep1c_ok(const mg_context* c, const Level& L) {
+    if (!c->march_sweeps || !L.cls || !c->class_sweeps || !L.sdia || L.wu != 4 || L.flat || !L.replicated) return false;
+    if (L.g.nx < 32 || L.g.ny < 32 || L.g.nk < 8) return false;
+    if (L.up[1] != 1 || L.up[2] != L.g.nx || (int64_t)L.up[3] != L.g.plane) return false;
+    return L.nloc >= c->march_min_rows;
+}
+
+template <int NW, int LPW>
+int launch_sweep1c_t(mg_context* c, J2Args& a, int mode) {
+    constexpr int EY = NW * LPW;
+    a.ntx = (a.nx + J2_EX - 3) / (J2_EX - 2);
+    a.nty = (a.ny + EY - 1) / EY;
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    // plane segments: enough work items for a few rounds of the CUs, each paying ~2.5 plane-times of warm-up
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    int best = 1;
+    double best_cost = 1e300;
+    for (int n = 1; n <= std::max(1, a.nz / 16); ++n) {
+        const double cost = (double)((ntile * n + cus - 1) / cus) * ((a.nz + n - 1) / n + 2.5);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    if (c->fuse_segments > 0) best = std::min(c->fuse_segments, a.nz);
+    a.seglen = (a.nz + best - 1) / best;
+    const int nseg = (a.nz + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    a.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
+    const int64_t group = 8 * (int64_t)a.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    constexpr size_t lds = j1c_lds_bytes<NW, LPW>();
+    void (*kern)(J2Args) = mode == MODE_RESIDUAL ? sdia_sweep1c<NW, LPW, MODE_RESIDUAL>
+                         : mode == MODE_GS ? sdia_sweep1c<NW, LPW, MODE_GS> : sdia_sweep1c<NW, LPW, MODE_JACOBI>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows, const double* f_rows, double* out_rows,
+                   int color) {
+    J2Args a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.nloc = L.nloc; a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
+    a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead; a.ncls = L.ncls; a.cmain = L.cmain;
+    for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+    a.color = color; a.color_kind = c->smoother == MG_SMOOTH_MCGS ? COLOR_LATTICE9 : COLOR_PARITY; a.grow0 = L.row0;
+    if (c->march_shape == 1) return launch_sweep1c_t<16, 2>(c, a, mode);
+    return launch_sweep1c_t<12, 2>(c, a, mode);
 }
 
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
@@ -1950,6 +2013,13 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_shape") {
         if (value < 0 || value > 3) return fail("fuse_shape must be 0..3");
         c->fuse_shape = (int)value;
+    } else if (k == "march_sweeps") {
+        c->march_sweeps = value != 0;
+    } else if (k == "march_min_rows") {
+        c->march_min_rows = value;
+    } else if (k == "march_shape") {
+        if (value < 0 || value > 1) return fail("march_shape must be 0 or 1");
+        c->march_shape = (int)value;
     } else if (k == "fuse_2d") {
         c->fuse_2d = value != 0;
     } else if (k == "fuse_2d_k") {

@@ -45,6 +45,9 @@ struct J2Args {
     double cm[8];           // passed by value (scalar registers)
     int wi;                 // class-coded pass: cells per tile line that get their second sweep (<= 124)
     unsigned xcd_chunk;     // consecutive work items per XCD at a time (the grid is a multiple of 8 * xcd_chunk)
+    // one-sweep march (sdia_sweep1c), MODE_GS: colour relaxed by this launch, its kind, global index of local row 0
+    int color, color_kind;
+    int64_t grow0;
     int nx, ny, nz;
     // plane segments: 0 = [0, zb), nseg-1 = [nz-zb, nz), the others cut [zb, nz-zb) into pieces of seglen planes;
     // this launch covers the segments seg0, seg0 + seg_stride, ... (nitems / (ntx*nty) of them)
@@ -722,6 +725,209 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
         load_x(k + 4, vd);
         __syncthreads();
     }
+}
+
+// ---- ONE sweep as a plane march on class-coded rows (residual, single Jacobi sweeps, Gauss-Seidel colours) -------
+// The slice kernels (sdia_cls_body) read a row's six x neighbours as unaligned 16-byte loads through L1; here the
+// pipeline of the pair pass is used for one sweep: a tile of 126 x EY result cells (+ the x ring inside the tile's
+// 128 cells per line, the y ring from the edge waves) marches through the planes, x of plane k in an LDS image,
+// x of planes k-1 / k+1 in registers, loads a step ahead.  Same entries, same order as sdia_cls_body: bit-identical.
+// MODE_GS relaxes the rows of one colour in place (out == x): a row only reads unknowns of other colours, which no
+// workgroup writes during the launch.
+template <int NW, int LPW> constexpr size_t j1c_lds_bytes() {
+    return sizeof(double) * (256 * CLS_W + 2 * (size_t)(NW * LPW + 2) * J2_EX + 2 * (J2_EX + 2));
+}
+
+template <int NW, int LPW, int MODE>
+__device__ __forceinline__ void j1c_body(const J2Args& a) {
+    constexpr int EX = J2_EX, EY = NW * LPW, NC = 2 * LPW;
+    extern __shared__ double j2_smem[];
+    constexpr int V0S = (EY + 2) * EX;
+    double* const sT = j2_smem;                           // 256 x 8   entries of the row classes, [7] = omega / diagonal
+    double* const sV0 = sT + 256 * CLS_W + (EX + 2);      // 2 x (EY+2) x EX   x of a plane, origin (0,-1)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3, ch = a.xcd_chunk;
+        id = ((j / ch) * 8u + xcd) * ch + (j % ch);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = (int)(id / ntile);
+    const unsigned t = id % ntile;
+    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
+    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    if (z1 <= z0) return;
+    constexpr int w1 = EX - 2;                            // result cells per line: ex = 1 .. w1
+    const int tx0 = tix * w1 - 1, ty0 = tiy * EY;         // grid position of cell (0, 0)
+
+    {
+        const int nt = a.ncls * CLS_W;
+        for (int i = threadIdx.x; i < nt; i += NW * WAVE) {
+            double v = a.ctab[i];
+            if ((i & (CLS_W - 1)) == CLS_W - 1) {
+                const double d = a.ctab[i - 4];
+                v = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+            }
+            sT[i] = v;
+        }
+    }
+    const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
+    const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    const int cmain = a.cmain;
+
+    const int ey0 = wave * LPW;
+    const int lw0 = ey0 * EX + lane;
+    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
+    unsigned inT = 0;           // bit c: this lane's cell c is a result cell on the grid
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
+        if (ex >= 1 && ex <= w1 && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
+    }
+    const bool wlo = wave == 0, whi = wave == NW - 1;
+
+    const unsigned bias = 2u * (unsigned)a.nx + 2u;
+    unsigned eo[NC], eor[2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        eo[c] = (unsigned)((int64_t)min(ty0 + ey0 + (c >> 1), a.ny + 1) * a.nx + tx0 + lane + 64 * (c & 1) + (int64_t)bias);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        eor[r] = (unsigned)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + lane + 64 * r + (int64_t)bias);
+    const unsigned char* const clsb = a.cls + a.clead - bias;
+    const double* const xb0 = a.x - bias;
+    const double* const fb0 = a.f - bias;
+    auto sbase = [](const void* p) -> gcptr_t {
+        const unsigned long long u = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+        return (gcptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    auto ldd = [](gcptr_t b, unsigned e) -> double {
+        return *(const __attribute__((address_space(1))) double*)(b + ((unsigned long long)e << 3));
+    };
+    auto ldc = [](gcptr_t b, unsigned e) -> int {
+        return *(const __attribute__((address_space(1))) unsigned char*)(b + (unsigned long long)e);
+    };
+
+    // registers per cell: x of planes k-1, k, k+1 (va vb vc) and k+2 (vd, in flight); f and the class of planes k and
+    // k+1 (in flight, with the y ring of x in plane k+1)
+    int c1[NC], c2[NC];
+    double f1[NC], f2[NC], va[NC], vb[NC], vc[NC], vd[NC];
+    double hy[2];
+    unsigned fast = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { f1[c] = f2[c] = va[c] = vb[c] = vc[c] = vd[c] = 0.0; c1[c] = c2[c] = 0; }
+    hy[0] = hy[1] = 0.0;
+
+    auto load_cf = [&](const int plane, int (&cc)[NC], double (&fr)[NC]) {
+        const int64_t o = (int64_t)min(max(plane, -1), a.nz) * a.P;
+        const gcptr_t cb = sbase(clsb + o);
+        const gcptr_t fb = sbase(fb0 + o);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            cc[c] = ldc(cb, eo[c]);
+            fr[c] = ldd(fb, eo[c]);
+        }
+        if (wlo || whi) {
+            const gcptr_t xb = sbase(xb0 + o);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) hy[r] = ldd(xb, eor[r]);
+        }
+    };
+    auto load_x = [&](const int plane, double (&v)[NC]) {
+        const gcptr_t xb = sbase(xb0 + (int64_t)min(max(plane, -1), a.nz) * a.P);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = ldd(xb, eo[c]);
+    };
+    auto park = [&](const int plane, const double (&v)[NC]) {
+        double* const xs = sV0 + (plane & 1) * V0S;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xs[lwof(c) + EX] = v[c];
+        if (wlo || whi) {
+            const int rowv = wlo ? 0 : (EY + 1) * EX;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) xs[rowv + lane + 64 * r] = hy[r];
+        }
+    };
+    auto all_main = [&](const int (&cc)[NC]) -> unsigned {
+        unsigned m = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(cc[c] != cmain) == 0ull))) m |= 1u << c;
+        return m;
+    };
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
+
+    // ---- warm-up: what step k = z0 finds in place ----
+    load_x(z0 - 1, va);
+    load_x(z0, vb);
+    load_x(z0 + 1, vc);
+    load_cf(z0, c1, f1);                    // (with the y ring of plane z0)
+    park(z0, vb);
+    fast = all_main(c1);
+    load_cf(z0 + 1, c2, f2);
+    load_x(z0 + 2, vd);
+    __syncthreads();
+
+    for (int k = z0; k < z1; ++k) {
+        const double* const x1 = sV0 + (k & 1) * V0S + EX;            // x of plane k, indexed by lwof
+        const int64_t o1 = (int64_t)k * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = lwof(c);
+            const double xs = x1[iw - EX], xw = x1[iw - 1], xe = x1[iw + 1], xn = x1[iw + EX];
+            double acc = 0.0, cf;
+            if (fast >> c & 1u) {
+                acc = fma(m0, va[c], acc);
+                acc = fma(m1, xs, acc);
+                acc = fma(m2, xw, acc);
+                acc = fma(m3, vb[c], acc);
+                acc = fma(m4, xe, acc);
+                acc = fma(m5, xn, acc);
+                acc = fma(m6, vc[c], acc);
+                cf = mcf;
+            } else {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c1[c]);
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                acc = fma(t01.x, va[c], acc);
+                acc = fma(t01.y, xs, acc);
+                acc = fma(t23.x, xw, acc);
+                acc = fma(t23.y, vb[c], acc);
+                acc = fma(t45.x, xe, acc);
+                acc = fma(t45.y, xn, acc);
+                acc = fma(t67.x, vc[c], acc);
+                cf = t67.y;
+            }
+            const int64_t r = rowof(c) + o1;
+            bool store = (inT >> c & 1u) != 0 && r >= 0 && r < a.nloc;
+            if (MODE == MODE_GS) store = store && lattice_color(a.color_kind, r + a.grow0, a.nx, a.ny) == a.color;
+            if (store) a.out[r] = MODE == MODE_RESIDUAL ? f1[c] - acc : vb[c] + cf * (f1[c] - acc);
+        }
+        // ---- park plane k+1, rotate, issue the loads of the step after the next ----
+        park(k + 1, vc);
+        fast = all_main(c2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            c1[c] = c2[c]; f1[c] = f2[c];
+            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+            asm volatile("" : "+v"(c1[c]));
+            asm volatile("" : "+v"(f1[c]));
+            asm volatile("" : "+v"(vc[c]));
+        }
+        load_cf(k + 2, c2, f2);
+        load_x(k + 3, vd);
+        __syncthreads();
+    }
+}
+
+template <int NW, int LPW, int MODE>
+__global__ __launch_bounds__(NW * WAVE) void sdia_sweep1c(J2Args a) {
+    j1c_body<NW, LPW, MODE>(a);
 }
 
 template <int NW, int LPW>

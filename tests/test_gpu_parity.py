@@ -1158,36 +1158,42 @@ def test_3d_cycles_converge_to_the_direct_solution():
     assert np.linalg.norm(v - u) <= 1e-9 * np.linalg.norm(u)
 
 
-def test_one_sweep_kernels_through_row_classes_are_bit_identical():
-    """`class_sweeps`: residual, single Jacobi sweeps, red-black Gauss-Seidel colours and the SpMV + dot of the PCG /
-    quadratic form read one class byte per row instead of the row where a level has row classes.  Same entries in the
-    same order: bit-identical to the plain symmetric-diagonal kernels, for every rows-per-lane setting."""
+@pytest.mark.parametrize("c,lo,hi", [(8, 2, 4), (5, 1, 4)])
+def test_one_sweep_kernels_through_row_classes_are_bit_identical(c, lo, hi):
+    """`class_sweeps`: residual, single Jacobi sweeps, Gauss-Seidel colours and the SpMV + dot of the PCG / quadratic
+    form read one class byte per row instead of the row where a level has row classes -- as persistent slice kernels
+    and, on whole 3-D levels, as a plane march with x in LDS (`march_sweeps`, both launch shapes).  Same entries in the
+    same order: bit-identical to the plain symmetric-diagonal kernels, for every rows-per-lane setting and for grids that
+    are not a multiple of the tile."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(3)
     for R in (1, 2, 4):
         outs = []
-        for cs in (0, 1):
-            with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=3, mu2=3, rows_per_lane=R, fuse_sweeps=0, class_sweeps=cs,
-                                           coarse_direct=0) as dev:                     # PCG coarsest solve: SpMV + dot
-                n = dev.level_info(4)["n_global"]
-                assert dev.level_info(4)["row_classes"] > 0
+        variants = [dict(class_sweeps=0), dict(march_sweeps=0), dict(march_min_rows=0), dict(march_min_rows=0, march_shape=1)]
+        for kw in variants if R == 2 else variants[:3]:
+            with DeviceHierarchy.synthetic(3, lo, hi, c=c, mu1=3, mu2=3, rows_per_lane=R, fuse_sweeps=0,
+                                           coarse_direct=0, **kw) as dev:                   # PCG coarsest solve: SpMV + dot
+                n = dev.level_info(hi)["n_global"]
+                assert dev.level_info(hi)["row_classes"] > 0
                 if not outs:
                     v_in, f_in = rng.standard_normal(n), rng.standard_normal(n)
                 got = []
-                dev.set_vector(4, "v", v_in)
-                dev.set_vector(4, "f", f_in)
-                dev.smooth(4, 3)
-                got.append(dev.get_vector(4, "v"))
-                dev.residual(4)
-                got.append(dev.get_vector(4, "r"))
-                got.append(np.array([dev.quadratic_form(4, "v")]))
-                dev.zero_vector(4, "v")
-                got.append(np.asarray(dev.vcycle(4, 2, residuals=True)))
-                got.append(dev.get_vector(4, "v"))
-                dev.set_params(2, 2, 1.0, smoother="rbgs")
-                dev.zero_vector(4, "v")
-                dev.vcycle(4, 1)
-                got.append(dev.get_vector(4, "v"))
+                dev.set_vector(hi, "v", v_in)
+                dev.set_vector(hi, "f", f_in)
+                dev.smooth(hi, 3)
+                got.append(dev.get_vector(hi, "v"))
+                dev.residual(hi)
+                got.append(dev.get_vector(hi, "r"))
+                got.append(np.array([dev.quadratic_form(hi, "v")]))
+                dev.zero_vector(hi, "v")
+                got.append(np.asarray(dev.vcycle(hi, 2, residuals=True)))
+                got.append(dev.get_vector(hi, "v"))
+                for sm in ("rbgs", "mcgs"):
+                    dev.set_params(2, 2, 1.0, smoother=sm)
+                    dev.zero_vector(hi, "v")
+                    dev.vcycle(hi, 1)
+                    got.append(dev.get_vector(hi, "v"))
                 outs.append(got)
-        for a, b in zip(*outs):
-            assert np.array_equal(a, b), R
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert np.array_equal(a, b), R
