@@ -255,9 +255,9 @@ def build_hierarchy(args, rv):
         device = rv.local_rank % max(1, torch.cuda.device_count())
     if args.config == "c5":
         if rv.world > 1:
-            raise SystemExit("config c5 (P2 rows reach two lattice planes) is single-GPU for now: the slab halo is one plane")
+            tuning["halo_planes"] = 2           # P2 rows reach two lattice planes
         return DeviceHierarchy.synthetic_p2(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega, device=device,
-                                            **tuning)
+                                            comm=comm, **tuning)
     return DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega,
                                      prune_zeros=True, device=device, comm=comm, **tuning)
 

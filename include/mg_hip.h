@@ -156,6 +156,8 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  *     "offset_codes"       0 keeps int32 column indices (1)
  *     "symmetric_storage"  0 keeps lower entries even for bit-for-bit symmetric matrices (1)
  *     "require_diagonal"   0 accepts operators without a diagonal, e.g. D^-1 R for mg_smooth_split (1)
+ *     "halo_planes"        grid planes exchanged with each slab neighbour: 1, or 2 for stencils that reach two planes
+ *                          (P2 lattice levels) (1)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
  *   any time:
  *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)

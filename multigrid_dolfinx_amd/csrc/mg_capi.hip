@@ -185,6 +185,7 @@ struct mg_context {
     hipStream_t comm_stream = nullptr;      // halo exchange overlapped with interior sweeps (world > 1)
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     int overlap = 1;
+    int halo_planes = 1;                    // grid planes exchanged with each slab neighbour (2: stencils that reach two planes, P2)
     int64_t overlap_min_rows = (int64_t)1 << 22;
     std::vector<Level> L;
     int mu1 = 50, mu2 = 50;
@@ -375,8 +376,9 @@ int setup_geometry(mg_context* c, Level& L, int level, int N, int64_t flat_rows 
         if (N0 < cm.world) return fail("coarsest grid has fewer planes than ranks");
         g.k0 = L.splits[cm.rank];
         g.nk = L.splits[cm.rank + 1] - g.k0;
-        L.halo_lo = cm.rank > 0 ? g.plane : 0;
-        L.halo_hi = cm.rank + 1 < cm.world ? g.plane : 0;
+        if ((N0 / cm.world) << level < c->halo_planes) return fail("a slab is thinner than the halo");
+        L.halo_lo = cm.rank > 0 ? c->halo_planes * g.plane : 0;
+        L.halo_hi = cm.rank + 1 < cm.world ? c->halo_planes * g.plane : 0;
     } else {
         g.k0 = 0;
         g.nk = g.nz;
@@ -650,13 +652,13 @@ int ensure_host_stage(mg_context* c, size_t elems) {
     return 0;
 }
 
-// Fill both halo planes of `v` from the neighbouring slabs (first owned plane goes down,
-// last owned plane goes up).
+// Fill the halo planes of `v` from the neighbouring slabs (the first `halo_planes` owned planes go down, the last ones
+// go up).
 int exchange_halo(mg_context* c, const Level& L, DVector& v, hipStream_t stream = nullptr) {
     if (!stream) stream = c->stream;
     Comm& cm = c->comm;
     if (L.replicated || !cm.active()) return 0;
-    const size_t plane = (size_t)L.g.plane;
+    const size_t plane = (size_t)c->halo_planes * (size_t)L.g.plane;       // elements per message
     const bool lo = cm.rank > 0, hi = cm.rank + 1 < cm.world;
     double* send_lo = v.rows;
     double* send_hi = v.rows + L.nloc - plane;
@@ -920,7 +922,6 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
 // Is lattice_color(COLOR_LATTICE9) a valid Gauss-Seidel colouring of the level's matrix?  (structure of the stored
 // non-zeros, in whatever format the level has)
 int check_coloring(mg_context* c, Level& L) {
-    if (L.halo_lo || L.halo_hi) { L.mc_ok = 0; return 0; }      // P2 rows reach two planes: whole levels only
     EllArgs a{};
     a.vals = L.vals; a.cols = L.cols; a.codes = L.codes; a.offsets = L.offsets; a.W = L.W;
     a.nloc = L.nloc; a.lead = L.g.lead; a.dinv = L.dinv; a.color_kind = COLOR_LATTICE9; a.grow0 = L.row0; a.gnx = L.g.nx; a.gny = L.g.ny;
@@ -1086,15 +1087,17 @@ int smooth(mg_context* c, int level, int nw) {
     }
     // slices that hold rows of the first / last owned plane: their results are what the neighbours need
     const int64_t S = (int64_t)WAVE * L.R;
-    const int64_t lo_end = std::min(L.nslices, (L.g.plane + S - 1) / S);
-    const int64_t hi_begin = std::max<int64_t>(lo_end, (L.nloc - L.g.plane) / S);
+    const int64_t hplanes = (int64_t)c->halo_planes * L.g.plane;
+    const int64_t lo_end = std::min(L.nslices, (hplanes + S - 1) / S);
+    const int64_t hi_begin = std::max<int64_t>(lo_end, (L.nloc - hplanes) / S);
     // below a few million rows a sweep is shorter than the extra launches and event hops of the overlapped
     // form: exchange in-stream there
     // (taken alike on every rank: every slab of a distributed level has at least 2^level >= 2 planes)
-    const bool two_planes = min_slab_rows(L) >= 2 * L.g.plane;
+    const bool two_planes = min_slab_rows(L) >= 2 * hplanes;
     const bool overlap = dist && c->overlap && two_planes && hi_begin > lo_end && c->comm_stream &&
                          min_slab_rows(L) >= c->overlap_min_rows;
-    const bool fused = fused_sweeps_ok(c, L) && (!dist || (two_planes && hi_begin > lo_end));
+    // (the paired pass on slabs is written for one halo plane)
+    const bool fused = fused_sweeps_ok(c, L) && (!dist || (c->halo_planes == 1 && two_planes && hi_begin > lo_end));
     J2Plan plan{};
     if (fused && nw > 1) {
         if (dist) MG_TRY(vec_alloc(c, L, &L.sw));
@@ -1998,6 +2001,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "lds_pad") {
         if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range");
         c->lds_pad = (int)value;
+    } else if (k == "halo_planes") {
+        if (value != 1 && value != 2) return fail("halo_planes must be 1 or 2");
+        for (auto& L : c->L)
+            if (L.set) return fail("halo_planes must be chosen before level set-up");
+        c->halo_planes = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0;
     } else if (k == "overlap_min_rows") {
@@ -2232,7 +2240,8 @@ int mg_gen_lattice_level(mg_handle c, int level, int N, int width, const int* co
     if (N <= 0 || (N & 1)) return fail("lattice levels need an even, positive number of lattice steps per dimension");
     if (!count || !offsets || !values || !load) return fail("null stencil tables");
     if (width < 1 || width > LAT_MAX) return fail("stencil width out of range");
-    if (c->comm.active()) return fail("lattice levels (two planes of reach) are single-GPU only");
+    if (c->comm.active() && c->halo_planes < 2)
+        return fail("lattice levels reach two planes: set mg_set_tuning(\"halo_planes\", 2) before mg_set_comm / level set-up");
     for (int p = 0; p < 8; ++p)
         if (count[p] < 0 || count[p] > width) return fail("a class has more entries than the stated width");
     HIP_TRY(hipSetDevice(c->device));

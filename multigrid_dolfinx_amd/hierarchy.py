@@ -233,9 +233,12 @@ class DeviceHierarchy:
 
     @classmethod
     def synthetic_p2(cls, dim: int, coarsest_level: int, finest_level: int, c: int = 8, mu1: int = 2, mu2: int = 2,
-                     omega: float = 1.0, smoother: str = "mcgs", device: int = 0, **tuning):
-        """Whole P2 hierarchy from the device generator (lattices of c * 2^level steps per dimension)."""
+                     omega: float = 1.0, smoother: str = "mcgs", device: int = 0, comm=None, **tuning):
+        """Whole P2 hierarchy from the device generator (lattices of c * 2^level steps per dimension); on slabs
+        (`comm`) the tuning must carry halo_planes=2: P2 rows reach two lattice planes."""
         h = cls(dim, coarsest_level, finest_level, c=c, device=device, **tuning)
+        if comm is not None:
+            comm(h)
         for level in range(coarsest_level, finest_level + 1):
             h.gen_p2_level(level)
         h.set_params(mu1, mu2, omega, smoother=smoother)

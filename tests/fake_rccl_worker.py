@@ -83,6 +83,63 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
     print(f"fake-rccl world={world} dim={dim} overlap={overlap}: OK")
 
 
+def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
+    """BASELINE config 5 on slabs: P2 lattice levels (two planes of reach -> halo_planes = 2), nine-colour
+    Gauss-Seidel and weighted Jacobi, against a single-handle run bit for bit."""
+    assert "fake_rccl" in os.environ.get("MG_RCCL_LIBRARY", "")
+    buf = C.create_string_buffer(128)
+    _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
+    uid = buf.raw
+    results, errors = [None] * world, []
+
+    def run(h):
+        out = []
+        for sm, om in (("mcgs", 1.0), ("jacobi", 0.6)):
+            h.set_params(mu, mu, om, smoother=sm)
+            h.zero_vector(hi, "v")
+            out.append(np.asarray(h.vcycle(hi, 2, residuals=True)))
+            out.append(h.get_vector(hi, "v", gather=True))
+        out.append(np.array([h.norm2(hi, "v")]))
+        return out
+
+    def rank_main(rank):
+        try:
+            def comm(h):
+                h.set_tuning("overlap", overlap)
+                h.set_tuning("overlap_min_rows", 0)
+                h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
+            h = DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, halo_planes=2)
+            info = h.level_info(hi)
+            assert not info["replicated"] and info["n_local"] < info["n_global"]
+            results[rank] = run(h)
+            h.close()
+        except Exception as exc:                                     # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            errors.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
+    assert not errors, errors
+    with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu) as ser:
+        want = run(ser)
+    for rank in range(world):
+        got = results[rank]
+        for k, (a, b) in enumerate(zip(got, want)):
+            if a.ndim == 1:                                          # residual histories / norms: all-reduced sums
+                assert np.all(np.abs(a - b) <= 1e-12 * np.abs(b)), (rank, k, a, b)
+            else:
+                assert np.array_equal(a, b), (rank, k, float(np.abs(a - b).max()))
+    print(f"fake-rccl P2 world={world} dim={dim} overlap={overlap}: OK")
+
+
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:9]]
-    main(*a)
+    if os.environ.get("MG_TEST_P2"):
+        main_p2(*a)
+    else:
+        main(*a)

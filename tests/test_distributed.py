@@ -95,3 +95,25 @@ def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "OK" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap", [(2, 3, 1, 3, 4, 0, 1), (3, 3, 1, 3, 4, 0, 0), (2, 2, 1, 4, 8, 0, 1),
+                                                        (4, 3, 1, 3, 4, 2000, 1)])
+def test_p2_levels_on_slabs_with_two_plane_halos(world, dim, lo, hi, c, rep, overlap):
+    """BASELINE config 5 distributed: P2 rows reach two lattice planes, so the slabs exchange two planes per neighbour
+    (`halo_planes` = 2).  Nine-colour Gauss-Seidel (a halo refresh after every colour) and weighted-Jacobi cycles on
+    2-4 slabs -- threads over the in-process RCCL stand-in -- equal the single-handle run bit for bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
+    env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_P2="1")
+    out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), str(dim), str(lo),
+                          str(hi), str(c), "2", str(rep), str(overlap)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "OK" in out.stdout
