@@ -112,10 +112,23 @@ int mg_set_comm_callbacks(mg_handle h, int rank, int world, mg_exchange_fn ex, m
  * multigrid.py:52-55, App. A Q7) and stores sliced-ELL tiles.  This subsumes
  * getJacobiMatrices (multigrid.py:48-56): D^-1 is extracted here and the smoother
  * streams A itself (v + w D^-1 (f - A v)), so no second matrix is stored.
- * In slab mode every rank passes the full matrix and keeps its own planes. */
+ * In slab mode every rank passes the full matrix (mg_set_level_csr_local takes the rank's rows only) and keeps its own planes. */
 int mg_set_level_csr(mg_handle h, int level, int elements_per_dim, int64_t n_rows, int64_t nnz,
                      const void* indptr, int indptr_is_64, const int32_t* indices,
                      const double* data, const int64_t* grid_index, int prune_zeros);
+/* Per-rank hand-off for slabs: the rank passes ONLY the rows it owns (mg_level_slab says which: the lexicographic
+ * nodes [row0, row0 + n_local) of the level, plus how many halo nodes it may couple to on either side), in a local
+ * numbering like a distributed assembly has it (PETSc's owned + ghost layout behind getValuesCSR(),
+ * Multigrid_prototype.py:95-96): row r of the CSR is local id r, column indices are local ids in [0, n_cols), and
+ * col_nodes[id] names the global lexicographic node of every local id (ids < n_rows: the owned rows, in any order; the
+ * rest: ghosts).  grid_index (n_global entries, or NULL for lexicographic) still maps the caller's GLOBAL DoF numbers to
+ * nodes for the vector calls.  Replicated levels take the whole matrix this way too (n_rows = n_global).  Results are
+ * those of the full-matrix hand-off bit for bit.  No reference counterpart (the reference is serial). */
+int mg_level_slab(mg_handle h, int level, int elements_per_dim, int64_t* row0, int64_t* n_local, int64_t* halo_lo,
+                  int64_t* halo_hi);
+int mg_set_level_csr_local(mg_handle h, int level, int elements_per_dim, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                           const void* indptr, int indptr_is_64, const int32_t* indices, const double* data,
+                           const int64_t* col_nodes, const int64_t* grid_index, int prune_zeros);
 /* A level with grid geometry and numbering only (no matrix): enough for the transfer
  * operators, which the reference exposes as free functions taking two coordinate
  * dictionaries (Interpolation2D / Restriction2D(_direct), multigrid.py:59, :123, :135). */

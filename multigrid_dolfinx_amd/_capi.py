@@ -42,6 +42,9 @@ SIGNATURES = {
     "mg_set_level_csr": [_H, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                          C.c_void_p, C.c_int],
     "mg_set_level_grid": [_H, C.c_int, C.c_int, C.c_int64, C.c_void_p],
+    "mg_level_slab": [_H, C.c_int, C.c_int, _i64p, _i64p, _i64p, _i64p],
+    "mg_set_level_csr_local": [_H, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
     "mg_gen_poisson_level": [_H, C.c_int, C.c_int, C.c_int],
     "mg_gen_lattice_level": [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mg_jacobi_split": [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -2095,9 +2095,12 @@ int upload_permutation(mg_context* c, Level& L, const int64_t* grid_index, int64
     return 0;
 }
 
+// `local_cols` (per-rank hand-off): the matrix holds this rank's owned rows only, its column indices are local ids in
+// [0, n_cols) and local_cols[id] is the global lexicographic node of each (ids 0 .. n_rows-1 are the rows themselves);
+// otherwise rows and columns are global DoF numbers and `grid_index` (or the identity) maps them to nodes.
 int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int64_t nnz, const void* indptr,
                          int indptr_is_64, const int32_t* indices, const double* data, const int64_t* grid_index,
-                         int prune_zeros, bool vectors = true) {
+                         int prune_zeros, bool vectors = true, const int64_t* local_cols = nullptr, int64_t n_cols = 0) {
     // upload the hand-off
     DevTemp d_ptr, d_idx, d_val;
     const size_t ptr_bytes = (size_t)(n_rows + 1) * (indptr_is_64 ? 8 : 4);
@@ -2107,10 +2110,35 @@ int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int
     HIP_TRY(hipMemcpyAsync(d_ptr.p, indptr, ptr_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_idx.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_val.p, data, (size_t)nnz * 8, hipMemcpyHostToDevice, c->stream));
-    MG_TRY(upload_permutation(c, L, grid_index, n_rows));
+    DevTemp d_map;
+    if (local_cols) {
+        // vectors keep crossing in the caller's GLOBAL numbering (grid_index, n_global entries); the matrix kernels see the
+        // local ids through their own map
+        MG_TRY(upload_permutation(c, L, grid_index, L.n_global));
+        std::vector<int> m32((size_t)n_cols);
+        std::vector<char> seen((size_t)L.nloc, 0);
+        const int64_t lo = L.row0 - L.halo_lo, hi = L.row0 + L.nloc + L.halo_hi;
+        for (int64_t d = 0; d < n_cols; ++d) {
+            const int64_t p = local_cols[d];
+            if (d < n_rows) {
+                if (p < L.row0 || p >= L.row0 + L.nloc || seen[(size_t)(p - L.row0)])
+                    return fail("the handed-over rows are not exactly this rank's slab of the level");
+                seen[(size_t)(p - L.row0)] = 1;
+            } else if (p < lo || p >= hi) {
+                return fail("a ghost column lies outside the slab's halo");
+            }
+            m32[(size_t)d] = (int)p;
+        }
+        MG_TRY(d_map.alloc((size_t)n_cols * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(d_map.p, m32.data(), (size_t)n_cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        MG_TRY(upload_permutation(c, L, grid_index, n_rows));
+    }
     CsrArgs a{};
     a.indptr = d_ptr.p; a.indptr64 = indptr_is_64; a.indices = static_cast<const int*>(d_idx.p); a.data = static_cast<const double*>(d_val.p);
-    a.perm = L.perm; a.n = n_rows; a.row0 = L.row0; a.nloc = L.nloc; a.lead = L.g.lead; a.xlen = L.xlen;
+    a.perm = local_cols ? static_cast<const int*>(d_map.p) : L.perm;
+    a.n = n_rows; a.row0 = L.row0; a.nloc = L.nloc; a.lead = L.g.lead; a.xlen = L.xlen;
     a.prune = prune_zeros;
     // pass 1: widest kept row, kept entries, sanity flags
     unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->partials);
@@ -2135,7 +2163,7 @@ int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int
     HIP_TRY(hipGetLastError());
     // true non-zeros among the kept entries (== kept when pruned); counted on the caller's copy (set-up only)
     L.nnz_nonzero = L.nnz_stored;
-    if (!prune_zeros && (!c->comm.active() || L.replicated)) {
+    if (!prune_zeros && (!c->comm.active() || L.replicated) && !local_cols) {
         unsigned long long nz = 0;
         for (int64_t q = 0; q < nnz; ++q) nz += data[q] != 0.0;
         L.nnz_nonzero = nz;
@@ -2166,6 +2194,41 @@ int mg_set_level_csr(mg_handle c, int level, int N, int64_t n_rows, int64_t nnz,
     if (rc) {
         const std::string why = g_err;
         free_level(c, L);           // never leave a half-built level behind
+        g_err = why;
+    }
+    return rc;
+}
+
+int mg_level_slab(mg_handle c, int level, int N, int64_t* row0, int64_t* n_local, int64_t* halo_lo, int64_t* halo_hi) {
+    MG_TRY(check_level(c, level, false));
+    if (N <= 0) return fail("elements_per_dim must be positive");
+    Level tmp;
+    MG_TRY(setup_geometry(c, tmp, level, N));
+    if (row0) *row0 = tmp.row0;
+    if (n_local) *n_local = tmp.nloc;
+    if (halo_lo) *halo_lo = tmp.halo_lo;
+    if (halo_hi) *halo_hi = tmp.halo_hi;
+    return 0;
+}
+
+int mg_set_level_csr_local(mg_handle c, int level, int N, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* indptr,
+                           int indptr_is_64, const int32_t* indices, const double* data, const int64_t* col_nodes,
+                           const int64_t* grid_index, int prune_zeros) {
+    MG_TRY(check_level(c, level, false));
+    if (!indptr || !indices || !data || !col_nodes) return fail("null CSR arrays");
+    if (N <= 0 || n_rows <= 0 || n_cols < n_rows || nnz < 0) return fail("bad matrix dimensions");
+    HIP_TRY(hipSetDevice(c->device));
+    Level& L = c->L[level];
+    free_level(c, L);
+    MG_TRY(setup_geometry(c, L, level, N));
+    if (n_rows != L.nloc)
+        return fail("the rank owns " + std::to_string(L.nloc) + " rows of this level (mg_level_slab), " + std::to_string(n_rows) +
+                    " were handed over");
+    const int rc = build_level_from_csr(c, level, L, n_rows, nnz, indptr, indptr_is_64, indices, data, grid_index, prune_zeros,
+                                        true, col_nodes, n_cols);
+    if (rc) {
+        const std::string why = g_err;
+        free_level(c, L);
         g_err = why;
     }
     return rc;

@@ -210,6 +210,29 @@ class DeviceHierarchy:
                                          ptr(indptr), is64, ptr(indices), ptr(data),
                                          ptr(gi) if gi is not None else None, 1 if prune_zeros else 0))
 
+    def level_slab(self, level: int):
+        """`(row0, n_local, halo_lo, halo_hi)`: the lexicographic nodes this rank owns on `level` and how many nodes
+        below / above them it may couple to (before the level is set)."""
+        v = [C.c_int64() for _ in range(4)]
+        check(self._lib.mg_level_slab(self._h, self._idx(level), self.elements(level), *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
+    def set_level_local(self, level: int, A_local, col_nodes, grid_index=None, prune_zeros: bool = True):
+        """Per-rank hand-off (`mg_set_level_csr_local`): `A_local` holds this rank's owned rows, its columns are local
+        ids and `col_nodes[id]` their global lexicographic nodes (the first `A_local.shape[0]` ids are the rows)."""
+        indptr, is64, indices, data = _csr_arrays(A_local)
+        cn = np.ascontiguousarray(col_nodes, dtype=np.int64)
+        if cn.size != A_local.shape[1]:
+            raise ValueError("col_nodes must name every local column")
+        gi = None
+        if grid_index is not None:
+            gi = np.ascontiguousarray(grid_index, dtype=np.int64)
+            if np.array_equal(gi, np.arange(gi.size)):
+                gi = None
+        check(self._lib.mg_set_level_csr_local(self._h, self._idx(level), self.elements(level), A_local.shape[0],
+                                               A_local.shape[1], data.size, ptr(indptr), is64, ptr(indices), ptr(data),
+                                               ptr(cn), ptr(gi) if gi is not None else None, 1 if prune_zeros else 0))
+
     def gen_poisson_level(self, level: int, prune_zeros: bool = True):
         """Device-side synthetic level (same tiles as `poisson.make_level` + `set_level`)."""
         check(self._lib.mg_gen_poisson_level(self._h, self._idx(level), self.elements(level),

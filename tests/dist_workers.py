@@ -83,7 +83,22 @@ def gpu_slab_worker(rank, world, port, dim, lo, hi, c, mu, replicate_below, mode
             ser = DeviceHierarchy(dim, lo, hi, c=c, **tuning)
             for h in (par, ser):
                 for l in range(lo, hi + 1):
-                    h.set_level(l, bag.A_sp_dict[l][0], gi[l])
+                    A = bag.A_sp_dict[l][0]
+                    if mode == "csr_local" and h is par:
+                        # per-rank hand-off: only the rows of this rank's slab, in a local numbering of its own
+                        # (owned nodes in reversed order, then the ghost nodes its rows couple to)
+                        row0, nloc, _, _ = h.level_slab(l)
+                        inv = np.empty_like(gi[l])
+                        inv[gi[l]] = np.arange(gi[l].size)
+                        A_lex = A.tocsr()[inv][:, inv].tocsr()
+                        owned = np.arange(row0, row0 + nloc)[::-1]
+                        rows = A_lex[owned]
+                        used = np.unique(rows.indices)
+                        ghosts = used[(used < row0) | (used >= row0 + nloc)]
+                        col_nodes = np.concatenate([owned, ghosts])
+                        h.set_level_local(l, rows[:, col_nodes].tocsr(), col_nodes, gi[l])
+                    else:
+                        h.set_level(l, A, gi[l])
                 h.set_params(mu, mu, bag.omega)
                 h.set_vector(hi, "f", f)
         info = par.level_info(hi)

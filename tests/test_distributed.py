@@ -35,6 +35,7 @@ def test_bench_rendezvous_over_gloo():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,dim,lo,hi,c,rep,mode", [(2, 2, 1, 3, 8, 1000, "csr"), (2, 3, 1, 3, 2, 200, "gen"),
+                                                        (2, 2, 1, 3, 8, 1000, "csr_local"), (3, 3, 1, 3, 4, 200, "csr_local"),
                                                          (2, 3, 1, 3, 4, 0, "gen"), (4, 3, 1, 3, 4, 0, "gen"),
                                                          (3, 2, 1, 3, 8, 1000, "csr")])
 def test_slabs_on_one_gpu_match_single_handle(world, dim, lo, hi, c, rep, mode):
