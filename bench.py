@@ -368,15 +368,17 @@ def main():
     def format_bytes_per_row(classes):
         """Bytes the shipped storage format MUST stream per row and launch: the matrix as stored
         + read x, read f, write out (+ D^-1 where it is streamed); one pass also when the launch does two sweeps."""
+        if classes:                                     # one class byte per row, whatever format holds the rows themselves
+            return 25
         if info["symmetric_diagonals"]:
-            return (1 if classes else 8 * info["symmetric_diagonals"]) + 24
+            return 8 * info["symmetric_diagonals"] + 24
         if info["offset_codes"]:
             return 8 * W + 8 * ((W + 7) // 8) + 24
         return 12 * W + 32
 
     sweeps_per_launch = (multi_k or 2) if pair_ms else 1
     dom_ms = pair_ms if pair_ms else (gs_ms if gs_ms else jac_ms)
-    dom_classes = classes_in_pair if pair_ms else classes_in_sweep
+    dom_classes = classes_in_pair if (pair_ms and not gs_ms) else classes_in_sweep
     fmt_row = format_bytes_per_row(dom_classes)
     bytes_launch = fmt_row * n_loc
     achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
@@ -384,7 +386,7 @@ def main():
     # formats do not move these bytes)
     csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
     if gs_ms:
-        kernel_id = "ell_apply_coded<0, 2, MODE_GS> x 9 colours"
+        kernel_id = ("ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif multi_k:
         kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
     elif pair_ms:

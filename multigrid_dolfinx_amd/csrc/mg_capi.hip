@@ -146,6 +146,12 @@ struct Level {
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
     int ncls = 0;
+    // stencil classes of an offset-coded level (mg_kernels.hip.h, ell_cls_apply): one byte per row + (offset, value) lists
+    unsigned char* scls = nullptr;
+    int* s_off = nullptr;
+    double* s_val = nullptr;
+    int* s_cnt = nullptr;
+    int nscls = 0;
     int cmain = 0;                          // the most frequent class and its entries (passed to the kernels by value)
     double cm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t cls_lead = 0, cls_rows = 0;     // cls[row + cls_lead], zero padding of cls_lead entries on both sides
@@ -415,6 +421,11 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.cls, (size_t)L.cls_rows);
     dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
+    dev_free(c, L.scls, (size_t)L.nslices * WAVE * L.R);
+    dev_free(c, L.s_off, (size_t)256 * L.W);
+    dev_free(c, L.s_val, (size_t)256 * L.W);
+    dev_free(c, L.s_cnt, 256);
+    L.nscls = 0;
     L.coded = false;
     L.rb_ok = false;
     L.mc_ok = -1;
@@ -519,6 +530,26 @@ void launch_sdia_r(int WU, int mode, bool dot, bool nt, bool finest, const EllAr
     }
 }
 
+template <int R, bool NT>
+void launch_ell_cls_rn(int mode, bool dot, const EllArgs& a, unsigned grid, hipStream_t s, const Level& L) {
+    if (mode == MODE_RESIDUAL)
+        hipLaunchKernelGGL((ell_cls_apply<R, MODE_RESIDUAL, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a, L.scls, L.s_off, L.s_val, L.s_cnt);
+    else if (mode == MODE_JACOBI)
+        hipLaunchKernelGGL((ell_cls_apply<R, MODE_JACOBI, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a, L.scls, L.s_off, L.s_val, L.s_cnt);
+    else if (mode == MODE_GS)
+        hipLaunchKernelGGL((ell_cls_apply<R, MODE_GS, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a, L.scls, L.s_off, L.s_val, L.s_cnt);
+    else if (dot)
+        hipLaunchKernelGGL((ell_cls_apply<R, MODE_SPMV, true, NT>), dim3(grid), dim3(BLOCK), 0, s, a, L.scls, L.s_off, L.s_val, L.s_cnt);
+    else
+        hipLaunchKernelGGL((ell_cls_apply<R, MODE_SPMV, false, NT>), dim3(grid), dim3(BLOCK), 0, s, a, L.scls, L.s_off, L.s_val, L.s_cnt);
+}
+
+template <int R>
+void launch_ell_cls_r(int mode, bool dot, bool nt, const EllArgs& a, unsigned grid, hipStream_t s, const Level& L) {
+    if (nt) launch_ell_cls_rn<R, true>(mode, dot, a, grid, s, L);
+    else launch_ell_cls_rn<R, false>(mode, dot, a, grid, s, L);
+}
+
 // offset codes are used for every width up to 64 entries per row (5, 7 and 15 have unrolled kernels)
 inline bool coded_width(int W) { return W >= 1 && W <= 64; }
 
@@ -612,6 +643,19 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
             case 1: launch_sdia_r<1>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
             case 2: launch_sdia_r<2>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
             case 4: launch_sdia_r<4>(L.wu, mode, dot, nt, finest, a, grid, c->stream, c->lds_pad); break;
+            default: return fail("unsupported rows_per_lane");
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (L.coded && L.scls && c->class_sweeps) {
+        // wide rows through their stencil classes: 25 bytes per row instead of the stored row (ell_cls_apply)
+        if (grid_out) *grid_out = grid;
+        const bool nt = c->nontemporal != 0;
+        switch (L.R) {
+            case 1: launch_ell_cls_r<1>(mode, dot, nt, a, grid, c->stream, L); break;
+            case 2: launch_ell_cls_r<2>(mode, dot, nt, a, grid, c->stream, L); break;
+            case 4: launch_ell_cls_r<4>(mode, dot, nt, a, grid, c->stream, L); break;
             default: return fail("unsupported rows_per_lane");
         }
         HIP_TRY(hipGetLastError());
@@ -1213,6 +1257,9 @@ int residual_restrict_fused(mg_context* c, int level) {
     a.vals = F.vals; a.cols = F.cols; a.codes = F.codes; a.offsets = F.offsets;
     a.x = F.v.base; a.f = F.f.rows; a.fc = C.f.base;
     a.W = F.W; a.R = F.R; a.coded = F.coded ? 1 : 0; a.gc = gc; a.gf = F.g;
+    if (F.coded && F.scls && c->class_sweeps) {
+        a.coded = 4; a.cls = F.scls; a.s_off = F.s_off; a.s_val = F.s_val; a.s_cnt = F.s_cnt;
+    }
     if (F.sdia) {
         a.vals = F.dvals; a.W = F.wu; a.coded = 2; a.mlead = F.mlead;
         for (int t = 0; t < 8; ++t) a.up[t] = F.up[t];
@@ -1682,6 +1729,62 @@ int build_row_classes(mg_context* c, Level& L) {
     for (int k = 1; k < L.ncls; ++k)
         if (L.cmain == 0 || hist[k] > hist[L.cmain]) L.cmain = k;
     for (int t = 0; t < 8; ++t) L.cm[t] = tab[(size_t)CLS_W * L.cmain + t];
+    return 0;
+}
+
+// Stencil classes of an offset-coded level that did not qualify for symmetric diagonals (wide stencils: P2): a
+// dictionary of its distinct rows -- the W (offset, value) pairs in stored order, bit for bit -- built and verified on
+// the device; levels with more than 255 distinct rows go without.
+int build_stencil_classes(mg_context* c, Level& L) {
+    if (!c->use_classes || !L.coded || L.sdia || L.flat || L.W < 8) return 0;
+    struct Scratch {
+        char* p = nullptr;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } scratch;
+    const size_t tag_bytes = SCLS_SLOTS * sizeof(unsigned long long), row_bytes = SCLS_SLOTS * sizeof(int64_t);
+    const size_t int_bytes = (2 + SCLS_SLOTS) * sizeof(int);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch.p), tag_bytes + row_bytes + int_bytes));
+    HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + row_bytes + int_bytes, c->stream));
+    int* const ints = reinterpret_cast<int*>(scratch.p + tag_bytes + row_bytes);
+    unsigned char* cls = nullptr;
+    int *s_off = nullptr, *s_cnt = nullptr;
+    double* s_val = nullptr;
+    const size_t crows = (size_t)L.nslices * WAVE * L.R;
+    MG_TRY(dev_alloc(c, &cls, crows));
+    MG_TRY(dev_alloc(c, &s_off, (size_t)256 * L.W));
+    MG_TRY(dev_alloc(c, &s_val, (size_t)256 * L.W));
+    MG_TRY(dev_alloc(c, &s_cnt, 256));
+    HIP_TRY(hipMemsetAsync(cls, 0, crows, c->stream));
+    HIP_TRY(hipMemsetAsync(s_off, 0, (size_t)256 * L.W * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(s_val, 0, (size_t)256 * L.W * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(s_cnt, 0, 256 * sizeof(int), c->stream));
+    SclsArgs a{};
+    a.vals = L.vals; a.codes = L.codes; a.offsets = L.offsets; a.W = L.W; a.dcode = L.dcode; a.nloc = L.nloc; a.nslices = L.nslices;
+    a.tags = reinterpret_cast<unsigned long long*>(scratch.p);
+    a.slot_row = reinterpret_cast<int64_t*>(scratch.p + tag_bytes);
+    a.count = ints; a.flag = ints + 1; a.slot_class = ints + 2;
+    a.cls = cls; a.s_off = s_off; a.s_val = s_val; a.s_cnt = s_cnt;
+    const dim3 grid(blocks_for(L.nloc, 256)), blk(256);
+    int h[2] = {0, 0};
+    int rc = [&]() -> int {
+        switch (L.R) {
+            case 1: hipLaunchKernelGGL(scls_insert<1>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(scls_assign<1>, dim3(1), blk, 0, c->stream, a);
+                    hipLaunchKernelGGL(scls_encode<1>, grid, blk, 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(scls_insert<2>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(scls_assign<2>, dim3(1), blk, 0, c->stream, a);
+                    hipLaunchKernelGGL(scls_encode<2>, grid, blk, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(scls_insert<4>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(scls_assign<4>, dim3(1), blk, 0, c->stream, a);
+                     hipLaunchKernelGGL(scls_encode<4>, grid, blk, 0, c->stream, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, ints, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    if (rc || h[0] > 255 || h[1]) {
+        dev_free(c, cls, crows); dev_free(c, s_off, (size_t)256 * L.W); dev_free(c, s_val, (size_t)256 * L.W); dev_free(c, s_cnt, 256);
+        return rc;
+    }
+    L.scls = cls; L.s_off = s_off; L.s_val = s_val; L.s_cnt = s_cnt; L.nscls = h[0];
     return 0;
 }
 
@@ -2171,6 +2274,7 @@ int build_level_from_csr(mg_context* c, int level, Level& L, int64_t n_rows, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     MG_TRY(encode_level(c, L));
     MG_TRY(repack_sdia(c, L, level));
+    MG_TRY(build_stencil_classes(c, L));
     L.has_matrix = true;
     if (!vectors) { L.set = true; return 0; }
     return finish_level(c, L);
@@ -2287,6 +2391,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     L.nnz_nonzero = counts[1];
     MG_TRY(encode_level(c, L));
     MG_TRY(repack_sdia(c, L, level));
+    MG_TRY(build_stencil_classes(c, L));
     // the generated right-hand side is also this level's true right-hand side for mg_fmg
     if (level + 1 < c->nlev) {
         MG_TRY(vec_alloc(c, L, &L.ftrue));
@@ -2343,6 +2448,7 @@ int mg_gen_lattice_level(mg_handle c, int level, int N, int width, const int* co
     L.nnz_nonzero = counts[1];
     MG_TRY(encode_level(c, L));
     MG_TRY(repack_sdia(c, L, level));
+    MG_TRY(build_stencil_classes(c, L));
     if (level + 1 < c->nlev) {
         MG_TRY(vec_alloc(c, L, &L.ftrue));
         HIP_TRY(hipMemcpyAsync(L.ftrue.base, L.f.base, (size_t)L.xlen * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -2410,7 +2516,7 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
 int mg_level_row_classes(mg_handle c, int level, int* classes) {
     MG_TRY(check_level(c, level));
     if (!classes) return fail("bad arguments");
-    *classes = c->L[level].cls ? c->L[level].ncls : 0;
+    *classes = c->L[level].cls ? c->L[level].ncls : c->L[level].nscls;
     return 0;
 }
 

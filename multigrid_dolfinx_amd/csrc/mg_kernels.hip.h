@@ -350,6 +350,179 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
     }
 }
 
+// ---- offset-coded rows read through stencil classes -------------------------------------------------
+// Wide stencils on structured meshes repeat as well: a P2 level has one row per parity class of the lattice point and
+// position next to the boundary (217 at most in 3-D).  Where an offset-coded level has at most 255 distinct rows --
+// the W (offset, value) pairs in stored order, bit for bit -- a row is one class byte and the pairs come from a table
+// in global memory that stays in L2 (classes x W x 12 bytes): 25 instead of 8 W + 8 ceil(W/8) + 24 bytes per row and
+// sweep (488 for 3-D P2).  Entries are applied in stored order like ell_apply_coded does (trailing padding skipped:
+// it adds 0 * x[row]), so results are the same.  All four modes; lanes of one wave run as many entries as their class has.
+struct SclsArgs {
+    const double* vals;                 // offset-coded ELL
+    const unsigned long long* codes;
+    const int* offsets;                 // code -> offset
+    int W, dcode;
+    int64_t nloc, nslices;
+    unsigned long long* tags;           // SCLS_SLOTS hash tags, 0 = free
+    int64_t* slot_row;                  // SCLS_SLOTS: a row that has the slot's stencil
+    int* count;                         // distinct rows seen
+    int* slot_class;                    // SCLS_SLOTS
+    unsigned char* cls;                 // nloc (+ padding): class of every row
+    int* s_off;                         // 256 x W
+    double* s_val;                      // 256 x W
+    int* s_cnt;                         // 256: entries in use per class (up to the last non-zero value)
+    int* flag;
+};
+constexpr int SCLS_SLOTS = 4096;
+
+template <int R> __device__ __forceinline__ unsigned long long scls_hash(const SclsArgs& a, int64_t row) {
+    constexpr int S = WAVE * R;
+    const int64_t slice = row / S, within = row % S;
+    const int CW = (a.W + 7) / 8;
+    unsigned long long h = 0x9e3779b97f4a7c15ull;
+    for (int k = 0; k < a.W; ++k) {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(a.vals[((size_t)slice * a.W + k) * S + within]);
+        const unsigned long long w = a.codes[((size_t)slice * CW + k / 8) * S + within];
+        const unsigned long long code = (w >> (8 * (k % 8))) & 0xffull;
+        unsigned long long x = h ^ (v + 0x3c6ef372fe94f82bull * (unsigned long long)(k + 1)) ^ (code << 56);
+        x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+        h = x;
+    }
+    return h ? h : 1ull;
+}
+
+template <int R> __device__ __forceinline__ bool scls_same(const SclsArgs& a, int64_t r0, int64_t r1) {
+    constexpr int S = WAVE * R;
+    const int CW = (a.W + 7) / 8;
+    const int64_t s0 = r0 / S, w0 = r0 % S, s1 = r1 / S, w1 = r1 % S;
+    for (int k = 0; k < a.W; ++k) {
+        if (__double_as_longlong(a.vals[((size_t)s0 * a.W + k) * S + w0]) != __double_as_longlong(a.vals[((size_t)s1 * a.W + k) * S + w1])) return false;
+        const unsigned long long c0 = (a.codes[((size_t)s0 * CW + k / 8) * S + w0] >> (8 * (k % 8))) & 0xffull;
+        const unsigned long long c1 = (a.codes[((size_t)s1 * CW + k / 8) * S + w1] >> (8 * (k % 8))) & 0xffull;
+        if (c0 != c1) return false;
+    }
+    return true;
+}
+
+template <int R>
+__global__ void scls_insert(SclsArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    const unsigned long long h = scls_hash<R>(a, row);
+    unsigned s = (unsigned)h & (SCLS_SLOTS - 1);
+    for (int probe = 0; probe < SCLS_SLOTS; ++probe) {
+        const unsigned long long seen = *(volatile unsigned long long*)(a.tags + s);
+        if (seen == h) return;
+        if (seen != 0ull) { s = (s + 1) & (SCLS_SLOTS - 1); continue; }
+        if (*(volatile int*)a.count > 255) return;
+        const unsigned long long old = atomicCAS(a.tags + s, 0ull, h);
+        if (old == 0ull) { a.slot_row[s] = row; atomicAdd(a.count, 1); return; }
+        if (old == h) return;
+        s = (s + 1) & (SCLS_SLOTS - 1);
+    }
+}
+
+// one block: classes 0, 1, ... in slot order; the table rows are copied from each slot's representative row
+template <int R>
+__global__ void scls_assign(SclsArgs a) {
+    constexpr int S = WAVE * R;
+    __shared__ int s_id[1];
+    if (threadIdx.x == 0) {
+        int id = 0;
+        for (int s = 0; s < SCLS_SLOTS; ++s) {
+            a.slot_class[s] = -1;
+            if (a.tags[s] && id < 256) a.slot_class[s] = id++;
+        }
+        s_id[0] = id;
+    }
+    __syncthreads();
+    const int CW = (a.W + 7) / 8;
+    for (int s = threadIdx.x; s < SCLS_SLOTS; s += blockDim.x) {
+        const int id = a.slot_class[s];
+        if (id < 0) continue;
+        const int64_t row = a.slot_row[s], slice = row / S, within = row % S;
+        int cnt = 0;
+        for (int k = 0; k < a.W; ++k) {
+            const double v = a.vals[((size_t)slice * a.W + k) * S + within];
+            const unsigned long long w = a.codes[((size_t)slice * CW + k / 8) * S + within];
+            a.s_val[(size_t)id * a.W + k] = v;
+            a.s_off[(size_t)id * a.W + k] = a.offsets[(int)((w >> (8 * (k % 8))) & 0xffull)];
+            if (v != 0.0) cnt = k + 1;
+        }
+        a.s_cnt[id] = cnt;
+    }
+}
+
+template <int R>
+__global__ void scls_encode(SclsArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nloc) return;
+    const unsigned long long h = scls_hash<R>(a, row);
+    unsigned s = (unsigned)h & (SCLS_SLOTS - 1);
+    for (int probe = 0; probe < SCLS_SLOTS; ++probe) {
+        const unsigned long long t = a.tags[s];
+        if (t == h) {
+            const int id = a.slot_class[s];
+            if (id < 0 || !scls_same<R>(a, row, a.slot_row[s])) atomicExch(a.flag, 1);     // overflow / hash collision
+            a.cls[row] = (unsigned char)(id < 0 ? 0 : id);
+            return;
+        }
+        if (t == 0ull) break;
+        s = (s + 1) & (SCLS_SLOTS - 1);
+    }
+    atomicExch(a.flag, 1);
+    a.cls[row] = 0;
+}
+
+// the four modes on class-coded wide rows (one wave = one slice, like ell_apply_coded)
+template <int R, int MODE, bool DOT, bool NT>
+__global__ __launch_bounds__(BLOCK) void ell_cls_apply(EllArgs a, const unsigned char* __restrict__ cls, const int* __restrict__ s_off,
+                                                        const double* __restrict__ s_val, const int* __restrict__ s_cnt) {
+    if (a.done_flag && *a.done_flag) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int64_t sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
+    double dot = 0.0;
+    if (MODE == MODE_GS && a.color_kind == COLOR_LATTICE9 && sl < a.nslices) {
+        const int64_t g0 = (a.slice0 + sl) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
+        const int64_t l0 = g0 / a.gnx, l1 = g1 / a.gnx;
+        const int want = (a.color == 8 ? 0 : a.color) >> 1;
+        bool any = l1 - l0 >= 4;
+        for (int64_t l = l0; l <= l1 && l < l0 + 4; ++l) any = any || ((int)((l % a.gny) & 1) | (int)(((l / a.gny) & 1) << 1)) == want;
+        if (!any) sl = a.nslices;
+    }
+    if (sl < a.nslices) {
+        const int64_t slice = a.slice0 + sl;
+        const int64_t row = slice * (WAVE * R) + (int64_t)lane * R;
+        const double* xrow = a.x + a.lead + row;
+        double acc[R], diag[R], xr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = 0.0; diag[r] = 1.0; xr[r] = 0.0;
+            if (row + r >= a.nloc) continue;
+            if (MODE == MODE_GS && lattice_color(a.color_kind, row + r + a.grow0, a.gnx, a.gny) != a.color) continue;
+            const int c = cls[row + r];
+            const int n = s_cnt[c];
+            const int* po = s_off + (size_t)c * a.W;
+            const double* pv = s_val + (size_t)c * a.W;
+            double s = 0.0;
+            for (int t = 0; t < n; ++t) {
+                const int off = po[t];
+                const double v = pv[t];
+                const double xv = xrow[r + off];
+                if (MODE != MODE_RESIDUAL && off == 0) { xr[r] = xv; if (v != 0.0) diag[r] = v; }
+                s = fma(v, xv, s);
+            }
+            acc[r] = s;
+        }
+        tile_epilogue<R, MODE, DOT, NT>(a, row, acc, diag, xr, dot);
+    }
+    if (DOT) {
+        const double t = block_sum(dot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+    }
+}
+
 // ---- symmetric diagonal storage ---------------------------------------------------------------
 // When a level's offsets are symmetric (o in the table <=> -o in the table, which every grid stencil
 // satisfies) and the matrix is bit-for-bit symmetric (a_ij == a_ji: checked at set-up), entry k of every
@@ -1098,6 +1271,8 @@ struct FusedRestrictArgs {
     Grid gc, gf;
     const unsigned char* cls;
     const double* ctab;
+    // coded == 4: offset-coded rows through stencil classes (cls row-based; s_off / s_val / s_cnt as ell_cls_apply)
+    const int* s_off; const double* s_val; const int* s_cnt;
 };
 
 __global__ void residual_inject(FusedRestrictArgs a) {
@@ -1116,7 +1291,12 @@ __global__ void residual_inject(FusedRestrictArgs a) {
     const int64_t slice = row / S, within = row % S;
     const size_t base = (size_t)slice * a.W * S + within;
     double acc = 0.0;
-    if (a.coded == 3) {
+    if (a.coded == 4) {
+        const int c = a.cls[row];
+        const int n = a.s_cnt[c];
+        const double* xrow = a.x + a.gf.lead + row;
+        for (int t = 0; t < n; ++t) acc = fma(a.s_val[(size_t)c * a.W + t], xrow[a.s_off[(size_t)c * a.W + t]], acc);
+    } else if (a.coded == 3) {
         const unsigned char* crow = a.cls + row;
         const double* xrow = a.x + a.gf.lead + row;
         const double* t = a.ctab + 8 * crow[0];             // the whole row: a(-P) a(-nx) a(-1) a(0) a(+1) a(+nx) a(+P)
