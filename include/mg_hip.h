@@ -163,6 +163,14 @@ int mg_jacobi_split(int device, int64_t n_rows, int64_t nnz, const void* indptr,
  * in for spsolve on the coarsest level (multigrid.py:239). */
 int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, int smoother,
                   double coarse_rtol, int coarse_maxit, int keep_err);
+/* Prolongation from a table instead of the reference's bilinear / trilinear Interpolation2D (multigrid.py:59-120): a fine
+ * lattice point (i, j, k) combines the count[r] coarse lattice points 2 * floor((i, j, k) / 4) + offsets[r][t] (each
+ * offset component 0..2, at most 10 entries) with weights[r][t], r = (i mod 4) + 4 (j mod 4) + 16 (k mod 4); 2-D levels
+ * use the residues with j mod 4 = 0.  With poisson.p2_prolongation_table this is the natural embedding of the coarse P2
+ * space into the fine one (BASELINE.json config 5; no reference counterpart).  All three NULL: back to the reference's
+ * interpolation.  Slabs need halo_planes = 2. */
+int mg_set_prolongation_table(mg_handle h, const int* count /*[64]*/, const int* offsets /*[64][10][3]*/,
+                              const double* weights /*[64][10]*/);
 /* Tuning and format knobs (defaults in parentheses; DESIGN.md sections 4-6 explain each):
  *   before any level is set:
  *     "rows_per_lane"      1 | 2 | 4 rows of a slice per lane (2)

@@ -51,6 +51,7 @@ SIGNATURES = {
                         C.c_void_p, C.c_void_p],
     "mg_set_params": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int],
     "mg_set_tuning": [_H, C.c_char_p, C.c_int64],
+    "mg_set_prolongation_table": [_H, C.c_void_p, C.c_void_p, C.c_void_p],
     "mg_level_info": [_H, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _ip, _ip, _ip],
     "mg_level_row_classes": [_H, C.c_int, _ip],
     "mg_set_vector": [_H, C.c_int, C.c_int, C.c_void_p],

@@ -249,6 +249,10 @@ struct mg_context {
     DirectSolver direct;
     // the reference's L2(Omega) norms (res_calculator / err_calculator, multigrid.py:203-218) on the device: a mass
     // matrix M of one level (mg_set_mass_csr), optionally the exact solution's nodal values (mg_set_exact)
+    // table prolongation (mg_set_prolongation_table; null: the reference's bilinear / trilinear interpolation)
+    int* ptab_count = nullptr;
+    int* ptab_off = nullptr;
+    double* ptab_w = nullptr;
     Level mass;
     int mass_level = -1;
     DVector mass_out, diff, uexact;
@@ -1278,6 +1282,21 @@ int prolong(mg_context* c, int level, int add) {
     Level& C = c->L[level - 1];
     const bool keep = !add || c->keep_err;
     if (keep) MG_TRY(vec_alloc(c, F, &F.err));
+    if (c->ptab_count) {
+        if (!F.replicated && c->comm.active() && c->halo_planes < 2)
+            return fail("the table prolongation reaches two coarse planes: halo_planes must be 2 on slabs");
+        const ProlongTable t{c->ptab_count, c->ptab_off, c->ptab_w};
+        const dim3 grid = grid3(F.g, F.g.nk), blk(kPlaneBlock);
+        if (add && keep)
+            hipLaunchKernelGGL((prolong_table<true, true>), grid, blk, 0, c->stream, C.g, F.g, t, C.v.base, F.v.base, F.err.base);
+        else if (add)
+            hipLaunchKernelGGL((prolong_table<true, false>), grid, blk, 0, c->stream, C.g, F.g, t, C.v.base, F.v.base, (double*)nullptr);
+        else
+            hipLaunchKernelGGL((prolong_table<false, true>), grid, blk, 0, c->stream, C.g, F.g, t, C.v.base, F.v.base, F.err.base);
+        HIP_TRY(hipGetLastError());
+        if (add) MG_TRY(exchange_halo(c, F, F.v));
+        return 0;
+    }
     // one thread per pair of fine nodes along x
     const int64_t pairs = (int64_t)((F.g.nx + 1) / 2) * F.g.ny;
     const dim3 grid((unsigned)((pairs + kPlaneBlock - 1) / kPlaneBlock), (unsigned)F.g.nk, 1u);
@@ -1941,6 +1960,7 @@ int mg_destroy(mg_handle c) {
     for (auto& L : c->L) free_level(c, L);
     free_level(c, c->mass);
     (void)hipFree(c->mass_out.raw); (void)hipFree(c->diff.raw); (void)hipFree(c->uexact.raw);
+    (void)hipFree(c->ptab_count); (void)hipFree(c->ptab_off); (void)hipFree(c->ptab_w);
     (void)hipFree(c->partials);
     (void)hipFree(c->scalars);
     (void)hipFree(c->done);
@@ -2065,6 +2085,30 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
     c->mu1 = mu1; c->mu2 = mu2; c->omega = omega; c->restriction = restriction; c->smoother = smoother;
     c->coarse_rtol = rtol; c->coarse_maxit = maxit;
     c->keep_err = keep_err;
+    return 0;
+}
+
+int mg_set_prolongation_table(mg_handle c, const int* count, const int* offsets, const double* weights) {
+    if (!c) return fail("null handle");
+    HIP_TRY(hipSetDevice(c->device));
+    ++c->epoch;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->ptab_count); (void)hipFree(c->ptab_off); (void)hipFree(c->ptab_w);
+    c->ptab_count = nullptr; c->ptab_off = nullptr; c->ptab_w = nullptr;
+    if (!count && !offsets && !weights) return 0;                 // back to the reference's interpolation
+    if (!count || !offsets || !weights) return fail("null table");
+    for (int r = 0; r < 64; ++r) {
+        if (count[r] < 0 || count[r] > 10) return fail("a residue has more than 10 entries");
+        for (int e = 0; e < count[r]; ++e)
+            for (int d = 0; d < 3; ++d)
+                if (offsets[(r * 10 + e) * 3 + d] < 0 || offsets[(r * 10 + e) * 3 + d] > 2) return fail("table offsets must be 0..2");
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ptab_count), 64 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ptab_off), 64 * 10 * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ptab_w), 64 * 10 * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->ptab_count, count, 64 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->ptab_off, offsets, 64 * 10 * 3 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->ptab_w, weights, 64 * 10 * sizeof(double), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -1409,6 +1409,39 @@ __global__ void prolong_correct(Grid gc, Grid gf, const double* __restrict__ vc,
     if (ADD) { vf[o] = vf[o] + e0; if (has_odd) vf[o + 1] = vf[o + 1] + e1; }
 }
 
+// Prolongation from a table (mg_set_prolongation_table): a fine lattice point combines the coarse lattice points
+// 2 * floor((i, j, k) / 4) + offset[residue][t] with weight[residue][t], residue = (i mod 4) + 4 (j mod 4) + 16 (k mod 4)
+// -- the natural embedding of the coarse P2 space on nested simplicial meshes (poisson.p2_prolongation_table; no
+// reference counterpart: Interpolation2D, multigrid.py:59-120, is the bilinear table).  Summed in table order,
+// multiply then add (no fma), as the oracle does.  Needs the coarse halo planes the offsets reach (up to two).
+struct ProlongTable {
+    const int* count;       // [64]
+    const int* off;         // [64][10][3]
+    const double* w;        // [64][10]
+};
+
+template <bool ADD, bool KEEP>
+__global__ void prolong_table(Grid gc, Grid gf, ProlongTable t, const double* __restrict__ vc, double* __restrict__ vf,
+                              double* __restrict__ err) {
+    int i, j;
+    if (!plane_node(gf, &i, &j)) return;
+    const int kl = blockIdx.y;
+    const int k = gf.k0 + kl;
+    const int res = (i & 3) | (gf.refine_y ? (j & 3) << 2 : 0) | (k & 3) << 4;
+    const int bi = 2 * (i >> 2), bj = gf.refine_y ? 2 * (j >> 2) : j, bk = 2 * (k >> 2);
+    const int n = t.count[res];
+    double s = 0.0;
+    for (int e = 0; e < n; ++e) {
+        const int* o = t.off + ((size_t)res * 10 + e) * 3;
+        const int64_t src = gc.lead + (int64_t)(bk + o[2] - gc.k0) * gc.plane + (int64_t)(bj + o[1]) * gc.nx + (bi + o[0]);
+        const double term = t.w[(size_t)res * 10 + e] * vc[src];
+        s = e == 0 ? term : s + term;
+    }
+    const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + i;
+    if (KEEP) err[o] = s;
+    if (ADD) vf[o] = vf[o] + s;
+}
+
 // ---- vector utilities ---------------------------------------------------------------------------
 __global__ void fill_zero(double* x, int64_t n) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)

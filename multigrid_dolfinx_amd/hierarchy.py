@@ -210,6 +210,21 @@ class DeviceHierarchy:
                                          ptr(indptr), is64, ptr(indices), ptr(data),
                                          ptr(gi) if gi is not None else None, 1 if prune_zeros else 0))
 
+    def set_prolongation(self, kind: str = "q1"):
+        """"q1": the reference's bilinear / trilinear interpolation (`Interpolation2D`); "p2": the natural embedding of
+        the coarse P2 space (`poisson.p2_prolongation_table`), for hierarchies of P2 lattice levels."""
+        if kind == "q1":
+            check(self._lib.mg_set_prolongation_table(self._h, None, None, None))
+            return
+        if kind != "p2":
+            raise ValueError("prolongation must be 'q1' or 'p2'")
+        from .poisson import p2_prolongation_table
+        cnt, off, w = p2_prolongation_table(self.dim)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        check(self._lib.mg_set_prolongation_table(self._h, ptr(cnt), ptr(off), ptr(w)))
+
     def level_slab(self, level: int):
         """`(row0, n_local, halo_lo, halo_hi)`: the lexicographic nodes this rank owns on `level` and how many nodes
         below / above them it may couple to (before the level is set)."""

@@ -391,3 +391,53 @@ def p2_stencils(dim: int):
             values[cls, t] = vv / h ** (dim - 2)
         load[cls] = L.b[node, 0] / h ** dim
     return count, offsets, values, load
+
+
+def p2_prolongation_table(dim: int):
+    """The natural prolongation between nested P2 spaces on the structured simplicial meshes (coarse cells of four
+    fine lattice steps per dimension): a fine lattice point takes the value of the coarse P2 function there.  That value
+    only depends on the point's position inside its coarse cell, `(i mod 4, j mod 4, k mod 4)`, so the operator is a table
+    `(count[64], offsets[64, 10, 3], weights[64, 10])`: for residue `ri + 4 rj + 16 rk` the `count` coarse lattice
+    points `2 * floor((i, j, k) / 4) + offsets` (coarse lattice units, 0..2 per axis) and their weights -- the P2 basis
+    functions `lambda_a (2 lambda_a - 1)` / `4 lambda_a lambda_b` of the Kuhn simplex that contains the point
+    (`x_p1 >= x_p2 >= x_p3` for the simplex of axis permutation p, as `p2_level` splits the cells).  Coincident points
+    copy, every other point combines up to 10 (3-D) / 6 (2-D) coarse values with weights like 3/8, 3/4, -1/8.
+    2-D lattices use the residues with `rj = 0` (device storage `(nx, 1, nz)`).  NO REFERENCE COUNTERPART
+    (`Interpolation2D` is bilinear, multigrid.py:59-120): BASELINE config 5's "higher-bandwidth transfer ops"."""
+    import itertools
+    axes = (0, 2) if dim == 2 else (0, 1, 2)            # lattice axes in use: (i, k) in 2-D
+    count = np.zeros(64, dtype=np.int32)
+    offsets = np.zeros((64, 10, 3), dtype=np.int32)
+    weights = np.zeros((64, 10))
+    for res in range(64):
+        r = (res & 3, (res >> 2) & 3, (res >> 4) & 3)
+        if dim == 2 and r[1]:
+            continue
+        x = np.array([r[a] / 4.0 for a in axes])         # position in the coarse cell
+        perm = sorted(range(dim), key=lambda d: (-x[d], d))
+        verts = [np.zeros(dim, dtype=int)]
+        for d in perm:
+            nxt = verts[-1].copy()
+            nxt[d] += 1
+            verts.append(nxt)
+        xs = [x[d] for d in perm]
+        lam = [1.0 - xs[0]] + [xs[t] - xs[t + 1] for t in range(dim - 1)] + [xs[-1]]
+        entries = {}
+        for a in range(dim + 1):
+            w = lam[a] * (2.0 * lam[a] - 1.0)
+            if w != 0.0:
+                entries[tuple(2 * verts[a])] = entries.get(tuple(2 * verts[a]), 0.0) + w
+        for a, b in itertools.combinations(range(dim + 1), 2):
+            w = 4.0 * lam[a] * lam[b]
+            if w != 0.0:
+                key = tuple(verts[a] + verts[b])
+                entries[key] = entries.get(key, 0.0) + w
+        keys = sorted(entries, key=lambda kk: tuple(reversed(kk)))           # ascending coarse lexicographic order
+        count[res] = len(keys)
+        for t, kk in enumerate(keys):
+            full = [0, 0, 0]
+            for d, a in enumerate(axes):
+                full[a] = kk[d]
+            offsets[res, t] = full
+            weights[res, t] = entries[kk]
+    return count, offsets, weights

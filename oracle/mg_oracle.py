@@ -137,6 +137,35 @@ class Oracle:
         return grid.reshape(-1)[self.grid_index[level]].reshape(-1, 1)
 
     # ---- transfers ----------------------------------------------------------------
+    def interpolate_table(self, vec_2h, level_coarse, table):
+        """Prolongation from a `(count, offsets, weights)` table (`poisson.p2_prolongation_table`: the natural embedding of
+        the coarse P2 space; the device's `prolong_table`): fine point (i, j, k) combines the coarse lattice points
+        `2 * floor((i, j, k) / 4) + offsets[r][t]`, r = (i mod 4) + 4 (j mod 4) + 16 (k mod 4), summed in table order,
+        multiply then add.  NO REFERENCE COUNTERPART."""
+        count, offsets, weights = table
+        lf = level_coarse + 1
+        nc1, nf1 = self.elements(level_coarse) + 1, self.elements(lf) + 1
+        gc = self._to_grid(vec_2h, level_coarse)                  # indexed [k][j][i] (3-D) or [k][i] (2-D)
+        idx = np.arange(nf1)
+        if self.dim == 3:
+            K, J, I = np.meshgrid(idx, idx, idx, indexing="ij")
+        else:
+            K, I = np.meshgrid(idx, idx, indexing="ij")
+            J = np.zeros_like(I)
+        res = (I & 3) | ((J & 3) << 2 if self.dim == 3 else 0) | ((K & 3) << 4)
+        bi, bj, bk = 2 * (I >> 2), (2 * (J >> 2) if self.dim == 3 else J), 2 * (K >> 2)
+        out = np.zeros(I.shape)
+        for r in np.unique(res):
+            m = res == r
+            acc = None
+            for t in range(count[r]):
+                a, b, c = bi[m] + offsets[r, t, 0], bj[m] + offsets[r, t, 1], bk[m] + offsets[r, t, 2]
+                vals = gc[c, b, a] if self.dim == 3 else gc[c, a]
+                term = weights[r, t] * vals
+                acc = term if acc is None else acc + term
+            out[m] = acc
+        return self._from_grid(out, lf)
+
     def interpolate(self, vec_2h, level_coarse):
         """Q1 prolongation coarse -> `level_coarse + 1`; follows `multigrid.py:59-120`.
 
@@ -245,7 +274,8 @@ class Oracle:
             f_2h = self.restrict_full_weighting(r_h, level)
         v_2h = np.zeros((f_2h.shape[0], 1))
         v_2h = self.v_cycle(self.A_jacobi_sp_dict[level - 1], v_2h, f_2h, test, restriction, smoother)
-        err_h = self.interpolate(v_2h, level - 1)
+        table = getattr(self, "prolongation_table", None)
+        err_h = self.interpolate(v_2h, level - 1) if table is None else self.interpolate_table(v_2h, level - 1, table)
         v_h = v_h + err_h
         v_h = self.smooth(A_h, v_h, f_h, self.mu2, smoother)
         if test and level == self.finest_level:

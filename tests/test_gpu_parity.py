@@ -823,6 +823,54 @@ def test_device_p2_generator_equals_the_assembled_levels(dim, c, lo, hi):
         assert rb[-1] < rb[0]
 
 
+@pytest.mark.parametrize("dim,cells,seed", [(2, (4, 8, 16), 6), (3, (2, 4, 8), None), (3, (4, 8, 16), 1)])
+def test_p2_table_prolongation_matches_oracle(dim, cells, seed):
+    """`mg_set_prolongation_table` with the natural P2 embedding (BASELINE config 5's transfer operator; no reference:
+    parity unpinned, the oracle's table prolongation is pinned to quadratic reproduction): bit-exact against the oracle,
+    whole cycles to the north-star tolerance, residuals fall monotonically, and switching back restores the bilinear
+    table's cycles.  (With the reference's injection of the finite-element residual -- SURVEY.md App. A Q1 -- the coarse
+    correction is under-scaled either way, so the prolongation alone changes the rate by a per cent or so.)"""
+    import types
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle
+    levels = {l: poisson.p2_level(N, dim, seed=seed) for l, N in enumerate(cells)}
+    c = 2 * cells[0]
+    bag = types.SimpleNamespace(
+        mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=c,
+        coarsest_level=0, finest_level=2, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+        b_dict={l: L.b for l, L in levels.items()}, mu0=2, mu1=2, mu2=2, omega=1.0,
+        residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None)
+    gi = {l: L.grid_index for l, L in levels.items()}
+    orc = Oracle(bag, gi, dim=dim)
+    table = poisson.p2_prolongation_table(dim)
+    rng = np.random.default_rng(2)
+    f = bag.b_dict[2]
+    with DeviceHierarchy.from_bag(bag, dim=dim, grid_index=gi) as dev:
+        dev.set_params(2, 2, 1.0, smoother="mcgs")
+        dev.set_vector(2, "f", f)
+        dev.zero_vector(2, "v")
+        res_q1 = dev.vcycle(2, 4, residuals=True)
+        dev.set_prolongation("p2")
+        for l in (0, 1):
+            vc = rng.standard_normal((levels[l].n, 1))
+            dev.set_vector(l, "v", vc)
+            dev.prolong(l + 1, add=False)
+            assert np.array_equal(dev.get_vector(l + 1, "err"), orc.interpolate_table(vc, l, table)), l
+        orc.prolongation_table = table
+        want = orc.v_cycle(orc.A_jacobi_sp_dict[2], np.zeros_like(f), f, smoother="mcgs")
+        assert rel_l2(_one_cycle(dev, 2, f), want) <= TOL_ITER
+        dev.zero_vector(2, "v")
+        res_p2 = dev.vcycle(2, 4, residuals=True)
+        assert np.all(res_p2[1:] < res_p2[:-1]) and res_p2[-1] < 1.05 * res_q1[-1], (res_q1, res_p2)
+        exact = levels[2].exact()
+        dev.set_vector(2, "v", exact)
+        dev.vcycle(2, 1)
+        assert rel_l2(dev.get_vector(2, "v"), exact) <= 1e-11
+        dev.set_prolongation("q1")
+        dev.zero_vector(2, "v")
+        assert np.all(np.abs(dev.vcycle(2, 4, residuals=True) - res_q1) <= 1e-12 * res_q1)
+
+
 def test_config5_full_size_properties():
     """BASELINE config 5 at its full size on one GPU (P2 on the 513^3-point lattice, 135 M unknowns, nine-colour
     Gauss-Seidel; no reference and no oracle at this size): properties that do not depend on the size -- the quadratic

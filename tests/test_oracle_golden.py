@@ -215,3 +215,39 @@ def test_nine_colour_gauss_seidel_oracle_against_plain_loops():
         C = L.A.tocoo()
         off = C.row != C.col
         assert not np.any(color[C.row[off]] == color[C.col[off]])
+
+
+def test_p2_prolongation_table_reproduces_quadratics():
+    """The table prolongation for nested P2 spaces (no reference counterpart) is pinned by what it is: the coarse P2
+    function evaluated at the fine lattice points.  P2 contains every quadratic, so nodal values of a random quadratic
+    on the coarse lattice must prolong to its nodal values on the fine lattice; coincident points copy; the weights of
+    every point sum to one."""
+    import types
+    from multigrid_dolfinx_amd import poisson
+    from oracle.mg_oracle import Oracle
+    for dim in (2, 3):
+        count, offsets, weights = poisson.p2_prolongation_table(dim)
+        used = [r for r in range(64) if count[r]]
+        assert len(used) == (16 if dim == 2 else 64)
+        assert all(abs(weights[r, :count[r]].sum() - 1.0) <= 1e-15 for r in used)
+        assert count[0] == 1 and weights[0, 0] == 1.0 and tuple(offsets[0, 0]) == (0, 0, 0)
+        assert count.max() == (5 if dim == 2 else 10) and weights.min() == -0.125
+        rng = np.random.default_rng(dim)
+        co = rng.standard_normal(10)
+
+        def q(c):
+            x, y, z = c[:, 0], c[:, 1], c[:, 2]
+            return (co[0] + co[1] * x + co[2] * y + co[3] * z + co[4] * x * x + co[5] * y * y + co[6] * z * z
+                    + co[7] * x * y + co[8] * x * z + co[9] * y * z).reshape(-1, 1)
+        levels = {l: poisson.p2_level(N, dim, seed=3 + l) for l, N in enumerate((2, 4))}
+        bag = types.SimpleNamespace(
+            mesh_dof_list_dict={}, element_size={}, coarsest_level_elements_per_dim=4, coarsest_level=0, finest_level=1,
+            A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={}, b_dict={l: L.b for l, L in levels.items()},
+            mu0=1, mu1=1, mu2=1, omega=1.0, residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None,
+            V_fine_dolfx=None)
+        orc = Oracle(bag, {l: L.grid_index for l, L in levels.items()}, dim=dim)
+        fine = orc.interpolate_table(q(levels[0].coords), 0, (count, offsets, weights))
+        assert np.abs(fine - q(levels[1].coords)).max() <= 1e-14
+        # the reference's bilinear table is exact for bilinear functions only
+        co[4:7] = 0.0
+        assert np.abs(orc.interpolate(q(levels[0].coords), 0) - q(levels[1].coords)).max() <= 1e-14
