@@ -46,7 +46,8 @@ enum mg_vec {
 
 enum mg_restriction {
     MG_RESTRICT_INJECTION = 0,      /* Restriction2D_direct, multigrid.py:123-132 (the live path, :251-252) */
-    MG_RESTRICT_FULL_WEIGHTING = 1  /* Restriction2D,        multigrid.py:135-198                            */
+    MG_RESTRICT_FULL_WEIGHTING = 1, /* Restriction2D,        multigrid.py:135-198                            */
+    MG_RESTRICT_TABLE = 2           /* transpose of the table prolongation (mg_set_restriction_table); no reference */
 };
 
 enum mg_smoother {
@@ -171,6 +172,14 @@ int mg_set_params(mg_handle h, int mu1, int mu2, double omega, int restriction, 
  * interpolation.  Slabs need halo_planes = 2. */
 int mg_set_prolongation_table(mg_handle h, const int* count /*[64]*/, const int* offsets /*[64][10][3]*/,
                               const double* weights /*[64][10]*/);
+/* Restriction from a table (MG_RESTRICT_TABLE), gathered per coarse lattice point: an interior coarse point A of type
+ * (a & 1) + 2 (b & 1) + 4 (c & 1) sums weights[type][t] * r[2 A + offsets[type][t]] over the interior fine points (offset
+ * components within +-4, max_entries per type); boundary coarse points take the coincident fine value.  With
+ * poisson.p2_restriction_table this is the transpose of the P2 prolongation, <R r, v> = <r, P v>: the canonical restriction of
+ * a finite-element residual (the reference injects it, multigrid.py:251-252, which under-scales the coarse correction:
+ * SURVEY.md App. A Q1).  Whole levels only.  No reference counterpart. */
+int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8]*/, const int* offsets /*[8][max][3]*/,
+                             const double* weights /*[8][max]*/);
 /* Tuning and format knobs (defaults in parentheses; DESIGN.md sections 4-6 explain each):
  *   before any level is set:
  *     "rows_per_lane"      1 | 2 | 4 rows of a slice per lane (2)

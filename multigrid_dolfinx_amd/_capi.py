@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 
 MG_VEC_V, MG_VEC_F, MG_VEC_R, MG_VEC_ERR = 0, 1, 2, 3
-MG_RESTRICT_INJECTION, MG_RESTRICT_FULL_WEIGHTING = 0, 1
+MG_RESTRICT_INJECTION, MG_RESTRICT_FULL_WEIGHTING, MG_RESTRICT_TABLE = 0, 1, 2
 MG_SMOOTH_JACOBI, MG_SMOOTH_RBGS, MG_SMOOTH_MCGS = 0, 1, 2
 MG_NORM_L2, MG_NORM_MASS = 0, 1
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "mg_set_params": [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int],
     "mg_set_tuning": [_H, C.c_char_p, C.c_int64],
     "mg_set_prolongation_table": [_H, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mg_set_restriction_table": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "mg_level_info": [_H, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _ip, _ip, _ip],
     "mg_level_row_classes": [_H, C.c_int, _ip],
     "mg_set_vector": [_H, C.c_int, C.c_int, C.c_void_p],

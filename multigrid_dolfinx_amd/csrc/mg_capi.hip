@@ -251,6 +251,10 @@ struct mg_context {
     // matrix M of one level (mg_set_mass_csr), optionally the exact solution's nodal values (mg_set_exact)
     // table prolongation (mg_set_prolongation_table; null: the reference's bilinear / trilinear interpolation)
     int* ptab_count = nullptr;
+    int* rtab_count = nullptr;              // table restriction (mg_set_restriction_table), MG_RESTRICT_TABLE
+    int* rtab_off = nullptr;
+    double* rtab_w = nullptr;
+    int rtab_m = 0;
     int* ptab_off = nullptr;
     double* ptab_w = nullptr;
     Level mass;
@@ -1240,7 +1244,12 @@ int restrict_to(mg_context* c, int level, int kind) {
     Level& F = c->L[level];
     Level& C = c->L[level - 1];
     Grid gc = coarse_target_grid(c, C, F);
-    if (kind == MG_RESTRICT_FULL_WEIGHTING) {
+    if (kind == MG_RESTRICT_TABLE) {
+        if (!c->rtab_count) return fail("no restriction table (mg_set_restriction_table)");
+        if (!F.replicated && c->comm.active()) return fail("the table restriction reaches three fine planes: whole levels only");
+        const RestrictTable t{c->rtab_count, c->rtab_off, c->rtab_w, c->rtab_m};
+        hipLaunchKernelGGL(restrict_table, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, gc, F.g, t, F.v2.base, C.f.base);
+    } else if (kind == MG_RESTRICT_FULL_WEIGHTING) {
         MG_TRY(exchange_halo(c, F, F.v2));
         hipLaunchKernelGGL(restrict_full_weighting, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, gc, F.g, F.v2.base,
                            C.f.base);
@@ -1961,6 +1970,7 @@ int mg_destroy(mg_handle c) {
     free_level(c, c->mass);
     (void)hipFree(c->mass_out.raw); (void)hipFree(c->diff.raw); (void)hipFree(c->uexact.raw);
     (void)hipFree(c->ptab_count); (void)hipFree(c->ptab_off); (void)hipFree(c->ptab_w);
+    (void)hipFree(c->rtab_count); (void)hipFree(c->rtab_off); (void)hipFree(c->rtab_w);
     (void)hipFree(c->partials);
     (void)hipFree(c->scalars);
     (void)hipFree(c->done);
@@ -2072,7 +2082,8 @@ int mg_set_params(mg_handle c, int mu1, int mu2, double omega, int restriction, 
                   int coarse_maxit, int keep_err) {
     if (!c) return fail("null handle");
     if (mu1 < 0 || mu2 < 0) return fail("mu1/mu2 must be >= 0");
-    if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
+    if (restriction != MG_RESTRICT_INJECTION && restriction != MG_RESTRICT_FULL_WEIGHTING && restriction != MG_RESTRICT_TABLE)
+        return fail("unknown restriction");
     if (smoother != MG_SMOOTH_JACOBI && smoother != MG_SMOOTH_RBGS && smoother != MG_SMOOTH_MCGS) return fail("unknown smoother");
     const double rtol = coarse_rtol > 0 ? coarse_rtol : c->coarse_rtol;
     const int maxit = coarse_maxit > 0 ? coarse_maxit : c->coarse_maxit;
@@ -2109,6 +2120,32 @@ int mg_set_prolongation_table(mg_handle c, const int* count, const int* offsets,
     HIP_TRY(hipMemcpy(c->ptab_count, count, 64 * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->ptab_off, offsets, 64 * 10 * 3 * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->ptab_w, weights, 64 * 10 * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mg_set_restriction_table(mg_handle c, int max_entries, const int* count, const int* offsets, const double* weights) {
+    if (!c) return fail("null handle");
+    HIP_TRY(hipSetDevice(c->device));
+    ++c->epoch;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->rtab_count); (void)hipFree(c->rtab_off); (void)hipFree(c->rtab_w);
+    c->rtab_count = nullptr; c->rtab_off = nullptr; c->rtab_w = nullptr; c->rtab_m = 0;
+    if (!count && !offsets && !weights) return 0;
+    if (!count || !offsets || !weights || max_entries < 1 || max_entries > 4096) return fail("bad restriction table");
+    for (int t = 0; t < 8; ++t) {
+        if (count[t] < 0 || count[t] > max_entries) return fail("a type has more entries than max_entries");
+        for (int e = 0; e < count[t]; ++e)
+            for (int d = 0; d < 3; ++d)
+                if (std::abs(offsets[((size_t)t * max_entries + e) * 3 + d]) > 4) return fail("table offsets must be within +-4");
+    }
+    const size_t n = (size_t)8 * max_entries;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->rtab_count), 8 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->rtab_off), n * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->rtab_w), n * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->rtab_count, count, 8 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->rtab_off, offsets, n * 3 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->rtab_w, weights, n * sizeof(double), hipMemcpyHostToDevice));
+    c->rtab_m = max_entries;
     return 0;
 }
 
@@ -2682,7 +2719,7 @@ int mg_restrict(mg_handle c, int level, int kind) {
     if (level == 0) return fail("level 0 has no coarser level");
     MG_TRY(need_grid(c, level));
     MG_TRY(need_grid(c, level - 1));
-    if (kind != MG_RESTRICT_INJECTION && kind != MG_RESTRICT_FULL_WEIGHTING) return fail("unknown restriction");
+    if (kind != MG_RESTRICT_INJECTION && kind != MG_RESTRICT_FULL_WEIGHTING && kind != MG_RESTRICT_TABLE) return fail("unknown restriction");
     HIP_TRY(hipSetDevice(c->device));
     return restrict_to(c, level, kind);
 }

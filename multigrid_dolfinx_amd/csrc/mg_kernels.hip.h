@@ -1442,6 +1442,44 @@ __global__ void prolong_table(Grid gc, Grid gf, ProlongTable t, const double* __
     if (ADD) vf[o] = vf[o] + s;
 }
 
+// Restriction from a table (mg_set_restriction_table): the transpose of the table prolongation, gathered per coarse
+// lattice point: an interior coarse point of type (a & 1) + 2 (b & 1) + 4 (c & 1) sums weight[type][t] * r[2 A + offset[type][t]]
+// over the INTERIOR fine points (the lifted system decouples the Dirichlet rows: a boundary coarse point takes the
+// coincident fine value, as injection does).  Summed in table order, multiply then add.  Whole levels only (reach +-3).
+struct RestrictTable {
+    const int* count;       // [8]
+    const int* off;         // [8][M][3]
+    const double* w;        // [8][M]
+    int M;
+};
+
+__global__ void restrict_table(Grid gc, Grid gf, RestrictTable t, const double* __restrict__ rf, double* __restrict__ fc) {
+    int i, j;
+    if (!plane_node(gc, &i, &j)) return;
+    const int kl = blockIdx.y;
+    const int K = gc.k0 + kl;
+    const int fi = 2 * i, fj = gf.refine_y ? 2 * j : j, fk = 2 * K;
+    const bool bnd = i == 0 || i == gc.nx - 1 || K == 0 || K == gc.nz - 1 || (gf.refine_y && (j == 0 || j == gc.ny - 1));
+    double s = 0.0;
+    if (bnd) {
+        s = rf[gf.lead + (int64_t)(fk - gf.k0) * gf.plane + (int64_t)fj * gf.nx + fi];
+    } else {
+        const int typ = (i & 1) | (gf.refine_y ? (j & 1) << 1 : 0) | (K & 1) << 2;
+        const int n = t.count[typ];
+        bool first = true;
+        for (int e = 0; e < n; ++e) {
+            const int* o = t.off + ((size_t)typ * t.M + e) * 3;
+            const int ii = fi + o[0], jj = fj + o[1], kk = fk + o[2];
+            if (ii <= 0 || ii >= gf.nx - 1 || kk <= 0 || kk >= gf.nz - 1) continue;
+            if (gf.refine_y && (jj <= 0 || jj >= gf.ny - 1)) continue;
+            const double term = t.w[(size_t)typ * t.M + e] * rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii];
+            s = first ? term : s + term;
+            first = false;
+        }
+    }
+    fc[gc.lead + (int64_t)kl * gc.plane + (int64_t)j * gc.nx + i] = s;
+}
+
 // ---- vector utilities ---------------------------------------------------------------------------
 __global__ void fill_zero(double* x, int64_t n) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)

@@ -23,7 +23,7 @@ __all__ = ["DeviceHierarchy", "jacobi_split"]
 
 _VEC = {"v": MG_VEC_V, "f": MG_VEC_F, "r": MG_VEC_R, "err": MG_VEC_ERR}
 _RESTRICT = {"direct": MG_RESTRICT_INJECTION, "injection": MG_RESTRICT_INJECTION,
-             "full_weighting": MG_RESTRICT_FULL_WEIGHTING}
+             "full_weighting": MG_RESTRICT_FULL_WEIGHTING, "table": _capi.MG_RESTRICT_TABLE}
 
 
 def _csr_arrays(A):
@@ -224,6 +224,13 @@ class DeviceHierarchy:
         off = np.ascontiguousarray(off, dtype=np.int32)
         w = np.ascontiguousarray(w, dtype=np.float64)
         check(self._lib.mg_set_prolongation_table(self._h, ptr(cnt), ptr(off), ptr(w)))
+        # ... and its transpose, selected with set_params(restriction="table")
+        from .poisson import p2_restriction_table
+        rc, ro, rw = p2_restriction_table(self.dim)
+        rc = np.ascontiguousarray(rc, dtype=np.int32)
+        ro = np.ascontiguousarray(ro, dtype=np.int32)
+        rw = np.ascontiguousarray(rw, dtype=np.float64)
+        check(self._lib.mg_set_restriction_table(self._h, int(ro.shape[1]), ptr(rc), ptr(ro), ptr(rw)))
 
     def level_slab(self, level: int):
         """`(row0, n_local, halo_lo, halo_hi)`: the lexicographic nodes this rank owns on `level` and how many nodes
@@ -271,15 +278,19 @@ class DeviceHierarchy:
 
     @classmethod
     def synthetic_p2(cls, dim: int, coarsest_level: int, finest_level: int, c: int = 8, mu1: int = 2, mu2: int = 2,
-                     omega: float = 1.0, smoother: str = "mcgs", device: int = 0, comm=None, **tuning):
+                     omega: float = 1.0, smoother: str = "mcgs", device: int = 0, comm=None, transfers: str = "q1",
+                     restriction: str = "direct", **tuning):
         """Whole P2 hierarchy from the device generator (lattices of c * 2^level steps per dimension); on slabs
-        (`comm`) the tuning must carry halo_planes=2: P2 rows reach two lattice planes."""
+        (`comm`) the tuning must carry halo_planes=2: P2 rows reach two lattice planes.  `transfers="p2"` +
+        `restriction="table"`: the P2 prolongation and its transpose instead of the reference's bilinear table / injection."""
         h = cls(dim, coarsest_level, finest_level, c=c, device=device, **tuning)
         if comm is not None:
             comm(h)
         for level in range(coarsest_level, finest_level + 1):
             h.gen_p2_level(level)
-        h.set_params(mu1, mu2, omega, smoother=smoother)
+        h.set_params(mu1, mu2, omega, smoother=smoother, restriction=restriction)
+        if transfers == "p2":
+            h.set_prolongation("p2")
         return h
 
     def set_params(self, mu1: int, mu2: int, omega: float, restriction: str = "direct",

@@ -441,3 +441,52 @@ def p2_prolongation_table(dim: int):
             offsets[res, t] = full
             weights[res, t] = entries[kk]
     return count, offsets, weights
+
+
+def p2_restriction_table(dim: int):
+    """Transpose of `p2_prolongation_table`, gathered per coarse lattice point: `(count[8], offsets[8, M, 3],
+    weights[8, M])` -- a coarse point A of type `(a & 1) + 2 (b & 1) + 4 (c & 1)` sums `weights[t] * r[2 A + offsets[t]]`
+    over the fine lattice points whose prolongation uses it (the canonical finite-element restriction of a residual:
+    `<R r, v> = <r, P v>`).  Entries in ascending fine lexicographic order.  NO REFERENCE COUNTERPART (the reference
+    restricts by injection, multigrid.py:123-132, :251-252)."""
+    count, offsets, weights = p2_prolongation_table(dim)
+    fwd = {}
+    for r in range(64):
+        for t in range(count[r]):
+            fwd[(r, tuple(int(x) for x in offsets[r, t]))] = weights[r, t]
+    axes_on = (True, dim == 3, True)
+    per_type = {}
+    rng = range(-4, 5)
+    for typ in range(8):
+        t = (typ & 1, (typ >> 1) & 1, (typ >> 2) & 1)
+        if dim == 2 and t[1]:
+            continue
+        ent = []
+        for dk in rng:
+            for dj in (rng if dim == 3 else (0,)):
+                for di in rng:
+                    d = (di, dj, dk)
+                    res, need, ok = 0, [], True
+                    for ax in range(3):
+                        if not axes_on[ax]:
+                            need.append(0)
+                            continue
+                        p = 2 * t[ax] + d[ax]                       # fine position relative to 4 q
+                        res |= (p % 4) << (2 * ax)
+                        o = t[ax] - 2 * (p // 4)                    # coarse offset that names A in that fine point's entry
+                        if o < 0 or o > 2:
+                            ok = False
+                        need.append(o)
+                    if ok and (res, tuple(need)) in fwd:
+                        ent.append((d, fwd[(res, tuple(need))]))
+        per_type[typ] = ent
+    M = max(len(v) for v in per_type.values())
+    rcount = np.zeros(8, dtype=np.int32)
+    roff = np.zeros((8, M, 3), dtype=np.int32)
+    rw = np.zeros((8, M))
+    for typ, ent in per_type.items():
+        rcount[typ] = len(ent)
+        for e, (d, w) in enumerate(ent):
+            roff[typ, e] = d
+            rw[typ, e] = w
+    return rcount, roff, rw

@@ -166,6 +166,44 @@ class Oracle:
             out[m] = acc
         return self._from_grid(out, lf)
 
+    def restrict_table(self, vec_h, level_fine, table):
+        """Restriction from a `(count, offsets, weights)` table gathered per coarse point (`poisson.p2_restriction_table`:
+        the transpose of the P2 prolongation; the device's `restrict_table`): interior coarse point A sums
+        `weights[type][t] * r[2 A + offsets[type][t]]` over the interior fine points, in table order, multiply then add;
+        boundary coarse points take the coincident fine value.  NO REFERENCE COUNTERPART."""
+        count, offsets, weights = table
+        lc = level_fine - 1
+        nc1, nf1 = self.elements(lc) + 1, self.elements(level_fine) + 1
+        gf = self._to_grid(vec_h, level_fine)
+        idx = np.arange(nc1)
+        if self.dim == 3:
+            K, J, I = np.meshgrid(idx, idx, idx, indexing="ij")
+        else:
+            K, I = np.meshgrid(idx, idx, indexing="ij")
+            J = np.zeros_like(I)
+        bnd = (I == 0) | (I == nc1 - 1) | (K == 0) | (K == nc1 - 1)
+        if self.dim == 3:
+            bnd |= (J == 0) | (J == nc1 - 1)
+        typ = (I & 1) | ((J & 1) << 1 if self.dim == 3 else 0) | ((K & 1) << 2)
+        out = np.zeros(I.shape)
+        out[bnd] = (gf[2 * K[bnd], 2 * J[bnd], 2 * I[bnd]] if self.dim == 3 else gf[2 * K[bnd], 2 * I[bnd]])
+        for t in np.unique(typ[~bnd]):
+            m = (typ == t) & ~bnd
+            acc = np.zeros(int(m.sum()))
+            started = np.zeros(int(m.sum()), dtype=bool)
+            for e in range(count[t]):
+                ii, jj, kk = 2 * I[m] + offsets[t, e, 0], 2 * J[m] + offsets[t, e, 1], 2 * K[m] + offsets[t, e, 2]
+                ok = (ii > 0) & (ii < nf1 - 1) & (kk > 0) & (kk < nf1 - 1)
+                if self.dim == 3:
+                    ok &= (jj > 0) & (jj < nf1 - 1)
+                ii, jj, kk = np.clip(ii, 0, nf1 - 1), np.clip(jj, 0, nf1 - 1), np.clip(kk, 0, nf1 - 1)
+                vals = gf[kk, jj, ii] if self.dim == 3 else gf[kk, ii]
+                term = weights[t, e] * vals
+                acc = np.where(ok, np.where(started, acc + term, term), acc)
+                started |= ok
+            out[m] = acc
+        return self._from_grid(out, lc)
+
     def interpolate(self, vec_2h, level_coarse):
         """Q1 prolongation coarse -> `level_coarse + 1`; follows `multigrid.py:59-120`.
 
@@ -270,6 +308,8 @@ class Oracle:
         r_h = f_h - self.A_sp_dict[level][0].dot(v_h)
         if restriction == "direct":
             f_2h = self.restrict_direct(r_h, level)
+        elif restriction == "table":
+            f_2h = self.restrict_table(r_h, level, self.restriction_table)
         else:
             f_2h = self.restrict_full_weighting(r_h, level)
         v_2h = np.zeros((f_2h.shape[0], 1))

@@ -251,3 +251,37 @@ def test_p2_prolongation_table_reproduces_quadratics():
         # the reference's bilinear table is exact for bilinear functions only
         co[4:7] = 0.0
         assert np.abs(orc.interpolate(q(levels[0].coords), 0) - q(levels[1].coords)).max() <= 1e-14
+
+
+def test_p2_restriction_table_is_the_transpose_of_the_prolongation():
+    """`<R r, v> = <r, P v>` for random vectors that vanish on the boundary (where the lifted system decouples and the
+    restriction injects): pins the gathered restriction table, its boundary handling and its index arithmetic to the
+    prolongation, which is itself pinned to quadratic reproduction."""
+    import types
+    from multigrid_dolfinx_amd import poisson
+    from oracle.mg_oracle import Oracle
+    for dim in (2, 3):
+        ptab, rtab = poisson.p2_prolongation_table(dim), poisson.p2_restriction_table(dim)
+        levels = {l: poisson.p2_level(N, dim, seed=5 + l) for l, N in enumerate((2, 4))}
+        bag = types.SimpleNamespace(
+            mesh_dof_list_dict={}, element_size={}, coarsest_level_elements_per_dim=4, coarsest_level=0, finest_level=1,
+            A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={}, b_dict={l: L.b for l, L in levels.items()},
+            mu0=1, mu1=1, mu2=1, omega=1.0, residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None,
+            V_fine_dolfx=None)
+        orc = Oracle(bag, {l: L.grid_index for l, L in levels.items()}, dim=dim)
+        rng = np.random.default_rng(dim)
+
+        def interior(L):
+            c = L.coords[:, :dim]
+            return np.all((c > 1e-12) & (c < 1 - 1e-12), axis=1).reshape(-1, 1)
+        r = rng.standard_normal((levels[1].n, 1)) * interior(levels[1])
+        v = rng.standard_normal((levels[0].n, 1)) * interior(levels[0])
+        lhs = float((orc.restrict_table(r, 1, rtab) * v).sum())
+        rhs = float((r * orc.interpolate_table(v, 0, ptab)).sum())
+        assert abs(lhs - rhs) <= 1e-12 * max(1.0, abs(rhs))
+        # boundary coarse points inject
+        r2 = rng.standard_normal((levels[1].n, 1))
+        got = orc.restrict_table(r2, 1, rtab)
+        inj = orc.restrict_direct(r2, 1)
+        b = ~interior(levels[0]).ravel()
+        assert np.array_equal(got[b], inj[b])
