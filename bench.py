@@ -298,11 +298,15 @@ def cpu_baseline(args):
     else:
         bag = poisson.make_hierarchy(dim, s_lo, s_hi, c=8, mu0=1, mu1=args.mu, mu2=args.mu, omega=args.omega)
     orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=dim)
+    if p2:                                      # the same transfer pair as the device run
+        orc.prolongation_table = poisson.p2_prolongation_table(dim)
+        orc.restriction_table = poisson.p2_restriction_table(dim)
     f = bag.b_dict[s_hi]
     v = np.zeros_like(f)
     cycles, t0 = 0, time.perf_counter()
     while cycles < 1 or (time.perf_counter() - t0 < 10.0 and cycles < 20):
-        v = orc.v_cycle(orc.A_jacobi_sp_dict[s_hi], v, f, smoother="mcgs" if p2 else "jacobi")
+        v = orc.v_cycle(orc.A_jacobi_sp_dict[s_hi], v, f, smoother="mcgs" if p2 else "jacobi",
+                        restriction="table" if p2 else "direct")
         cycles += 1
     dt = time.perf_counter() - t0
     n_s = bag.levels[s_hi].n
