@@ -355,7 +355,13 @@ def main():
         pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
     except Exception:
         pair_ms = None
-    multi_k = 0
+    multi_k, small = 0, False
+    if pair_ms is None:
+        try:    # levels of a few thousand rows: all mu sweeps of a smoother call in one launch (sdia_jacobi_small)
+            pair_ms = h.time_kernel("jacobi_small", hi, args.kernel_reps)
+            multi_k, small = args.mu, True
+        except Exception:
+            pair_ms = None
     if pair_ms is None:
         try:    # 2-D levels with row classes: up to five sweeps per launch (sdia_jacobik2d)
             pair_ms = h.time_kernel("jacobik", hi, args.kernel_reps)
@@ -393,6 +399,8 @@ def main():
     csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
     if gs_ms:
         kernel_id = ("ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
+    elif small:
+        kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
     elif multi_k:
         kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
     elif pair_ms:

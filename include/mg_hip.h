@@ -215,6 +215,8 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          plane march with x in LDS on whole 3-D seven-point levels (1); bit-identical either way
  *     "march_min_rows"     ... only on levels with at least this many rows (4194304)
  *     "march_shape"        ... 0 = 12 waves x 2 grid lines per workgroup, 1 = 16 x 2 (0)
+ *     "fuse_small"         all Jacobi sweeps of a smoother call in ONE launch on levels with row classes that fit one CU's
+ *                          LDS (a few thousand rows: the reference's own 65^2 / 33^2 levels) (1); bit-identical
  *     "fuse_2d"            up to "fuse_2d_k" Jacobi sweeps per launch on 2-D five-point levels with row classes (1);
  *                          bit-identical to single sweeps
  *     "fuse_2d_k"          ... at most this many per launch, 2..5 (5)
@@ -304,6 +306,7 @@ int mg_counters(mg_handle h, int64_t* uploads, int64_t* downloads, int64_t* grap
  * one kernel of the path on `level`, measured with HIP events on the handle's own
  * stream ("jacobi", "residual", "restrict", "prolong", "norm2"; "jacobi2" = the two-sweep pass, an
  * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies;
+ * "jacobi_small" = the mu1 sweeps of a small level in one launch, an error where mg_smooth does not do that;
  * "jacobik" = one launch of the K-sweep 2-D kernel with K = "fuse_2d_k", an error on levels that do not use it;
  * "gs" = one full Gauss-Seidel sweep, all colours, with the configured Gauss-Seidel smoother).
  * Used by bench.py for the roofline figure.  mg_sync waits for the handle's stream. */

@@ -242,6 +242,7 @@ struct mg_context {
     int march_sweeps = 1;           // one-sweep class kernels as a plane march on large 3-D levels (sdia_sweep1c)
     int64_t march_min_rows = (int64_t)1 << 22;
     int march_shape = 0;            // 0 = 12 waves x 2 lines, 1 = 16 waves x 2 lines
+    int fuse_small = 1;             // all sweeps of a level that fits one CU's LDS in one launch (sdia_jacobi_small)
     int fuse_2d = 1;                // K sweeps per launch on 2-D levels with row classes (sdia_jacobik2d)
     int fuse_2d_k = 5;              // ... at most this many (2..5)
     int fuse_xcd_chunk = 32;        // consecutive tiles of that pass per XCD at a time
@@ -1094,6 +1095,30 @@ int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows
     return launch_sweep1c_t<12, 2>(c, a, mode);
 }
 
+// All sweeps of a small level in one launch (mg_jacobi2.hip.h, sdia_jacobi_small): whole five- / seven-point levels with
+// row classes that fit one CU's LDS.
+bool small_level_ok(const mg_context* c, const Level& L) {
+    if (!c->fuse_small || !L.sdia || !L.cls || !c->fuse_classes || L.flat || !L.replicated) return false;
+    if (L.wu != 3 && L.wu != 4) return false;
+    if (L.up[1] != 1 || L.up[2] <= 1 || (L.wu == 4 && L.up[3] <= L.up[2])) return false;
+    const int pad = L.wu == 4 ? L.up[3] : L.up[2];
+    return L.nloc <= 16384 && js_lds_bytes((int)L.nloc, pad) <= (size_t)150 * 1024;
+}
+
+int launch_jacobi_small(mg_context* c, const Level& L, int nw, const double* x_rows, const double* f_rows, double* out_rows) {
+    JSArgs a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.cls = L.cls + L.cls_lead; a.ctab = L.ctab; a.ncls = L.ncls; a.cmain = L.cmain;
+    for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+    a.n = (int)L.nloc; a.nw = nw; a.up1 = L.up[1]; a.up2 = L.up[2]; a.up3 = L.wu == 4 ? L.up[3] : 0; a.omega = c->omega;
+    const size_t lds = js_lds_bytes(a.n, L.wu == 4 ? a.up3 : a.up2);
+    void (*kern)(JSArgs) = L.wu == 4 ? sdia_jacobi_small<4> : sdia_jacobi_small<3>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)150 * 1024));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
@@ -1125,6 +1150,11 @@ int smooth(mg_context* c, int level, int nw) {
         return 0;
     }
     const bool dist = !L.replicated && c->comm.active();
+    if (!dist && nw >= 2 && small_level_ok(c, L)) {
+        MG_TRY(launch_jacobi_small(c, L, nw, L.v.rows, L.f.rows, L.v2.rows));
+        std::swap(L.v, L.v2);
+        return 0;
+    }
     if (!dist && sweeps2d_ok(c, L)) {
         // 2-D levels: up to fuse_2d_k sweeps per launch, the rest (at most one) as a single sweep
         int left = nw;
@@ -2212,6 +2242,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "march_shape") {
         if (value < 0 || value > 1) return fail("march_shape must be 0 or 1");
         c->march_shape = (int)value;
+    } else if (k == "fuse_small") {
+        c->fuse_small = value != 0;
     } else if (k == "fuse_2d") {
         c->fuse_2d = value != 0;
     } else if (k == "fuse_2d_k") {
@@ -2985,6 +3017,10 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             if (!fused_sweeps_ok(c, L, k == "jacobi2!")) return fail("level does not use the two-sweep kernel");
             const J2Plan plan = jacobi2_plan(c, L, false, 0);
             return launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows);
+        }
+        if (k == "jacobi_small") {           // all mu1 sweeps of a small level in one launch
+            if (!small_level_ok(c, L) || c->mu1 < 2) return fail("level does not use the one-launch smoother");
+            return launch_jacobi_small(c, L, c->mu1, L.v.rows, L.f.rows, L.v2.rows);
         }
         if (k == "jacobik") {
             if (!sweeps2d_ok(c, L)) return fail("level does not use the K-sweep 2-D kernel");

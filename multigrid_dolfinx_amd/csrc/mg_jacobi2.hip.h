@@ -1070,3 +1070,94 @@ __global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
 }
 
 }  // namespace mgk
+
+namespace mgk {
+
+// ---- all sweeps of a small level in one launch ------------------------------------------------------------------
+// The reference's shipped configuration (Multigrid_prototype.py:35-46) smooths levels of 4225 and 1089 unknowns fifty
+// times per leg: such a level (x twice, f, class bytes: 25 bytes per row) fits the LDS of one CU, so ONE 1024-thread
+// workgroup runs all nw sweeps with a barrier between them -- one launch instead of nw (or nw / 5).  Rows are handled
+// in linear row space with zero padding of the largest offset on both sides; arithmetic of sdia_cls_body<WU, ...>:
+// bit-identical to single sweeps.  Five- and seven-point levels with row classes.
+struct JSArgs {
+    const double* x;        // row-based
+    const double* f;
+    double* out;
+    const unsigned char* cls;       // row-based
+    const double* ctab;
+    int ncls, cmain;
+    double cm[8];
+    int n, nw;
+    int up1, up2, up3;      // the positive offsets (+1, +nx, +plane; up3 = 0 for five-point rows)
+    double omega;
+};
+
+inline size_t js_lds_bytes(int n, int pad) { return (size_t)256 * CLS_W * 8 + (size_t)2 * (n + 2 * pad) * 8 + (size_t)n * 8 + (size_t)n; }
+
+template <int WU>
+__global__ __launch_bounds__(1024) void sdia_jacobi_small(JSArgs a) {
+    extern __shared__ double j2_smem[];
+    const int n = a.n, pad = WU == 4 ? a.up3 : a.up2, stride = n + 2 * pad;
+    double* const sT = j2_smem;
+    double* const sX = sT + 256 * CLS_W;                      // 2 x (pad | n | pad)
+    double* const sF = sX + 2 * stride;
+    unsigned char* const sC = reinterpret_cast<unsigned char*>(sF + n);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * stride; i += 1024) sX[i] = 0.0;
+    for (int i = tid; i < a.ncls * CLS_W; i += 1024) {
+        double v = a.ctab[i];
+        if ((i & (CLS_W - 1)) == CLS_W - 1) {
+            const double d = a.ctab[i - 4];
+            v = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+        }
+        sT[i] = v;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) {
+        sX[pad + r] = a.x[r];
+        sF[r] = a.f[r];
+        sC[r] = a.cls[r];
+    }
+    const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
+    const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    __syncthreads();
+    for (int s = 0; s < a.nw; ++s) {
+        const double* const src = sX + (s & 1) * stride + pad;
+        double* const dst = sX + ((s + 1) & 1) * stride + pad;
+        for (int r0 = 0; r0 < n; r0 += 1024) {
+            const int r = r0 + tid;
+            const bool in = r < n;
+            const int rr = in ? r : n - 1;
+            const int c = sC[rr];
+            const double xc = src[rr];
+            double acc = 0.0, cf;
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != a.cmain) == 0ull))) {
+                if (WU == 4) acc = fma(m0, src[rr - a.up3], acc);
+                acc = fma(m1, src[rr - a.up2], acc);
+                acc = fma(m2, src[rr - a.up1], acc);
+                acc = fma(m3, xc, acc);
+                acc = fma(m4, src[rr + a.up1], acc);
+                acc = fma(m5, src[rr + a.up2], acc);
+                if (WU == 4) acc = fma(m6, src[rr + a.up3], acc);
+                cf = mcf;
+            } else {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                if (WU == 4) acc = fma(t01.x, src[rr - a.up3], acc);
+                acc = fma(t01.y, src[rr - a.up2], acc);
+                acc = fma(t23.x, src[rr - a.up1], acc);
+                acc = fma(t23.y, xc, acc);
+                acc = fma(t45.x, src[rr + a.up1], acc);
+                acc = fma(t45.y, src[rr + a.up2], acc);
+                if (WU == 4) acc = fma(t67.x, src[rr + a.up3], acc);
+                cf = t67.y;
+            }
+            if (in) dst[r] = xc + cf * (sF[r] - acc);
+        }
+        __syncthreads();
+    }
+    const double* const res = sX + (a.nw & 1) * stride + pad;
+    for (int r = tid; r < n; r += 1024) a.out[r] = res[r];
+}
+
+}  // namespace mgk

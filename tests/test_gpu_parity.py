@@ -1061,7 +1061,7 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    variants = [dict(fuse_sweeps=0), dict(), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0), dict(fuse_shape=0), dict(fuse_shape=3), dict(fuse_shape=2, fuse_segments=2),
+    variants = [dict(fuse_sweeps=0, fuse_small=0), dict(), dict(fuse_sweeps=0), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0), dict(fuse_shape=0), dict(fuse_shape=3), dict(fuse_shape=2, fuse_segments=2),
                 dict(fuse_segments=5, fuse_nontemporal=1, fuse_classes=0), dict(rows_per_lane=1),
                 dict(rows_per_lane=4, fuse_segments=2), dict(rows_per_lane=1, row_classes=0)]
     for kw in variants:
@@ -1153,7 +1153,8 @@ def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    for kw in (dict(fuse_2d=0), dict(), dict(fuse_2d_k=2), dict(fuse_2d_k=3), dict(fuse_2d_k=4), dict(rows_per_lane=1)):
+    for kw in (dict(fuse_2d=0, fuse_small=0), dict(), dict(fuse_small=0), dict(fuse_small=0, fuse_2d_k=2), dict(fuse_2d_k=3),
+               dict(fuse_small=0, fuse_2d_k=4), dict(rows_per_lane=1)):
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
         with DeviceHierarchy.synthetic(2, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
@@ -1173,14 +1174,14 @@ def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi
                     got = dev.get_vector(level, "v")
                     if not kw:
                         assert dev.time_kernel("jacobik", level, 1) > 0.0
-                    if kw == dict(fuse_2d=0):
+                    if kw == dict(fuse_2d=0, fuse_small=0):
                         want[level, nw] = got
                     else:
                         assert np.array_equal(got, want[level, nw]), (kw, level, nw)
             dev.set_params(50, 49, 2.0 / 3.0)
             dev.zero_vector(hi, "v")
             res = dev.vcycle(hi, 3, residuals=True)
-            if kw == dict(fuse_2d=0):
+            if kw == dict(fuse_2d=0, fuse_small=0):
                 want["res"] = res
             else:
                 assert np.all(np.abs(res - want["res"]) <= 1e-13 * want["res"]), kw
