@@ -204,6 +204,10 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
  *     "fuse_classes"       that pass reads one class byte per row instead of the 32-byte row where the level has
  *                          row classes (1); bit-identical either way
+ *     "fuse_plain"         that pass on levels WITHOUT row classes: 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's (2);
+ *                          bit-identical either way
+ *     "fuse_plain_shape"   ... its launch shape: 0 = 12 waves x 1 grid line, 1 = 8 x 2, 2 = 16 x 1 (0: the only one without
+ *                          register spills, measured best)
  *     "class_sweeps"       the one-sweep kernels (residual, single sweeps, SpMV, Gauss-Seidel colours) read the class
  *                          byte too where the level has row classes (1); bit-identical either way
  *     "fuse_shape"         launch shape of the class-coded pass: 0 = 8 waves x 2 grid lines, 1 = 12 waves x 2 lines,

@@ -234,6 +234,8 @@ struct mg_context {
     int fuse_segments = 0;          // plane segments per tile (0: chosen from the item count)
     int fuse_nontemporal = 0;       // streaming loads in the two-sweep kernel (measured slower: tiles re-read their rims)
     int fuse_classes = 1;           // the two-sweep pass reads row classes where the level has them
+    int fuse_plain_shape = 0;       // ... its launch shape: 0 = 12 waves x 1 line (no spills), 1 = 8 x 2, 2 = 16 x 1
+    int fuse_plain = 2;             // the pass on the stored rows (no classes): 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's
     int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
@@ -845,7 +847,7 @@ struct J2Plan { int ntx, nty, nseg, zb, seglen, wi; };
 // grid lines per tile: 16 for the plain pass; the class-coded pass has shapes with 16 and 32 ("fuse_shape")
 int jacobi2_lines(const mg_context* c, const Level& L) {
     const int sh = c->fuse_shape;
-    if (!(L.cls && c->fuse_classes)) return kJ2Lines;
+    if (!(L.cls && c->fuse_classes)) return (c->fuse_plain == 2 && c->fuse_plain_shape == 0) ? 12 : kJ2Lines;
     return (sh == 1 || sh == 3) ? 24 : kJ2Lines;
 }
 
@@ -854,8 +856,8 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     const int lines = jacobi2_lines(c, L);
     p.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
     p.nty = (L.g.ny + lines - 3) / (lines - 2);
-    if (L.cls && c->fuse_classes) {
-        // class-coded pass: the x ring is part of the tile (124 cells with a second sweep at most), and all tile
+    if ((L.cls && c->fuse_classes) || c->fuse_plain == 2) {
+        // class-coded pass / round-2 plain pass: the x ring is part of the tile (124 cells with a second sweep at most), and all tile
         // columns have the same width, the smallest that covers the grid ("fuse_even" 0: always the widest)
         p.ntx = (L.g.nx + J2_EX - 5) / (J2_EX - 4);
         p.wi = c->fuse_even ? (L.g.nx + p.ntx - 1) / p.ntx : J2_EX - 4;
@@ -920,6 +922,23 @@ int launch_jacobi2c_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
 }
 
 template <int R, int NW, int LPW>
+int launch_jacobi2p_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
+    const int64_t items = (int64_t)a.ntx * a.nty * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    J2Args b = a;
+    b.nitems = (unsigned)items;
+    b.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
+    const int64_t group = 8 * (int64_t)b.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    constexpr size_t lds = j2p_lds_bytes<NW, LPW>();
+    void (*const kern[2])(J2Args) = {sdia_jacobi2p<R, NW, LPW>, sdia_jacobi2p_finest<R, NW, LPW>};
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
+    hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, b);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int R, int NW, int LPW>
 int launch_jacobi2_t(mg_context* c, const J2Args& a, int nseg, bool finest) {
     static_assert(NW * LPW == kJ2Lines, "tile height");
     const int64_t items = (int64_t)a.ntx * a.nty * nseg;
@@ -966,6 +985,22 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
             case 3: return launch_jacobi2c_t<8, 3>(c, a, n, finest);       // 24 lines, 512 threads
             default: return launch_jacobi2c_t<12, 2>(c, a, n, finest);     // 24 lines, 768 threads (measured best)
         }
+    }
+    if (c->fuse_plain == 2) {            // round-2 structure of the pass on the stored rows (sdia_jacobi2p)
+        a.wi = plan.wi;
+        if (c->fuse_plain_shape == 0) {  // 12 waves x 1 grid line (155 VGPRs, no spills: measured best)
+            if (L.R == 2) return launch_jacobi2p_t<2, 12, 1>(c, a, n, finest);
+            if (L.R == 1) return launch_jacobi2p_t<1, 12, 1>(c, a, n, finest);
+            return launch_jacobi2p_t<4, 12, 1>(c, a, n, finest);
+        }
+        if (c->fuse_plain_shape == 2) {  // 16 waves x 1 grid line
+            if (L.R == 2) return launch_jacobi2p_t<2, 16, 1>(c, a, n, finest);
+            if (L.R == 1) return launch_jacobi2p_t<1, 16, 1>(c, a, n, finest);
+            return launch_jacobi2p_t<4, 16, 1>(c, a, n, finest);
+        }
+        if (L.R == 2) return launch_jacobi2p_t<2, 8, 2>(c, a, n, finest);
+        if (L.R == 1) return launch_jacobi2p_t<1, 8, 2>(c, a, n, finest);
+        return launch_jacobi2p_t<4, 8, 2>(c, a, n, finest);
     }
     if (L.R == 2) return launch_jacobi2_t<2, 8, 2>(c, a, n, finest);
     if (L.R == 1) return launch_jacobi2_t<1, 8, 2>(c, a, n, finest);
@@ -2261,6 +2296,12 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_even = value != 0;
     } else if (k == "class_sweeps") {
         c->class_sweeps = value != 0;
+    } else if (k == "fuse_plain_shape") {
+        if (value < 0 || value > 2) return fail("fuse_plain_shape must be 0..2");
+        c->fuse_plain_shape = (int)value;
+    } else if (k == "fuse_plain") {
+        if (value != 1 && value != 2) return fail("fuse_plain must be 1 or 2");
+        c->fuse_plain = (int)value;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;
     } else if (k == "fuse_nontemporal") {

@@ -727,6 +727,241 @@ __device__ __forceinline__ void j2c_body(const J2Args& a) {
     }
 }
 
+// ---- the two-sweep pass on the stored rows, round-2 structure (levels without row classes) ---------------------
+// j2_body above is round 1's pass; its address selects (`ok ? p : zero`) under lane conditions were compiled into
+// exec-masked branches with a full vmcnt(0) inside, and the take-over copies sat behind the next loads.  This is the
+// same march in the structure of j2c_body: the x ring is part of the tile (126 first-sweep cells, 124 with a second
+// sweep per 128-cell line), every load is unconditional (rows outside the level read the stored zeros at `zero`: an
+// address select, no branch), loads are issued a step ahead and taken over before the next ones are issued.  The
+// lower entries of a row are its neighbours' upper entries: -P from the cell's own previous plane (register), -1 / -nx
+// through LDS images of the +1 / +nx diagonals of the plane being relaxed once; the two values a cell reads there are
+// kept in registers for its second sweep one step later, so the images need two slots only.
+// Same entries, same fma order, same IEEE division as sdia_body: bit-identical to two single sweeps.
+template <int NW, int LPW> constexpr size_t j2p_lds_bytes() {
+    constexpr int EY = NW * LPW;
+    return sizeof(double) * (2 * (size_t)(EY + 2) * J2_EX + 2 * (size_t)EY * J2_EX + 2 * (size_t)EY * J2_EX +
+                             2 * (size_t)(EY + 1) * J2_EX + 4 * (J2_EX + 2));
+}
+
+template <int R, int NW, int LPW>
+__device__ __forceinline__ void j2p_body(const J2Args& a) {
+    constexpr int S = WAVE * R, EX = J2_EX, EY = NW * LPW, NC = 2 * LPW;
+    extern __shared__ double j2_smem[];
+    constexpr int V0S = (EY + 2) * EX, V1S = EY * EX, QS = (EY + 1) * EX;
+    double* const sV0 = j2_smem + (EX + 2);               // 2 x (EY+2) x EX   x of a plane, origin (0,-1)
+    double* const sV1 = sV0 + 2 * V0S;                    // 2 x EY x EX       once-relaxed iterate of a plane
+    double* const sP = sV1 + 2 * V1S + (EX + 2);          // 2 x EY x EX       +1 diagonal of a plane
+    double* const sQ = sP + 2 * V1S + (EX + 2);           // 2 x (EY+1) x EX   +nx diagonal of a plane, origin (0,-1)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3, ch = a.xcd_chunk;
+        id = ((j / ch) * 8u + xcd) * ch + (j % ch);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = a.seg0 + (int)(id / ntile) * a.seg_stride;
+    const unsigned t = id % ntile;
+    const int tiy = (int)(t / (unsigned)a.ntx), tix = (int)(t % (unsigned)a.ntx);
+    int z0, z1;
+    if (seg == 0) { z0 = 0; z1 = min(a.zb, a.nz); }
+    else if (seg == a.nseg - 1) { z0 = max(a.nz - a.zb, a.zb); z1 = a.nz; }
+    else { z0 = a.zb + (seg - 1) * a.seglen; z1 = min(a.nz - a.zb, z0 + a.seglen); }
+    if (z1 <= z0) return;
+    const int wi = a.wi, w1 = wi + 2;
+    const int tx0 = tix * wi - 2, ty0 = tiy * (EY - 2) - 1;
+
+    const int ey0 = wave * LPW;
+    const int lw0 = ey0 * EX + lane;
+    auto lwof = [&](int c) -> int { return lw0 + (c >> 1) * EX + 64 * (c & 1); };
+    unsigned inT = 0, lineT = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ex = lane + 64 * (c & 1), ey = ey0 + (c >> 1);
+        const bool line = ey >= 1 && ey < EY - 1 && ty0 + ey < a.ny && 64 * (c & 1) < w1;
+        if (line) lineT |= 1u << c;
+        if (line && ex >= 2 && ex < w1 && tx0 + ex < a.nx) inT |= 1u << c;
+    }
+    const bool wlo = wave == 0, whi = wave == NW - 1;
+
+    // rows of the cells in plane 0 (grid lines from ny+2 on are read at line ny+1, see j2c_body); the y ring's line
+    int rw[NC], rwr[2];                     // (a level has fewer than 2^31 rows)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        rw[c] = (int)((int64_t)min(ty0 + ey0 + (c >> 1), a.ny + 1) * a.nx + tx0 + min(lane + 64 * (c & 1), w1 + 1));
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        rwr[r] = (int)((int64_t)(wlo ? ty0 - 1 : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + min(lane + 64 * r, w1 + 1));
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c >> 1) * a.nx + 64 * (c & 1); };
+    // the diagonal slot of a stored row, or the stored zeros for rows the level does not have
+    auto mat = [&](int64_t row) -> const double* {
+        const uint64_t m = (uint64_t)(row + a.mlead);
+        const double* p = a.vals + (size_t)(m / S) * (4 * S) + (size_t)(m % S);
+        return (row >= a.slo && row < a.nloc) ? p : a.zero;
+    };
+    auto xat = [&](int64_t row) -> const double* { return (row >= a.xlo && row < a.xhi) ? a.x + row : a.zero; };
+    auto fat = [&](int64_t row) -> const double* { return (row >= 0 && row < a.nloc) ? a.f + row : a.zero; };
+
+    // plane k: matrix row, f, the two lower entries read at its first sweep, the +P entry of plane k-1;
+    // plane k+1; plane k+2 (in flight); x of planes k .. k+3; the once-relaxed iterate of planes k-1 .. k+1
+    double d0[NC], p0[NC], q0[NC], s0[NC], f0[NC], pw0[NC], qs0[NC], tm[NC];      // tm = (+P entry of plane k-1) * v1[k-1]
+    double d1[NC], p1[NC], q1[NC], s1[NC], f1[NC];
+    double d2[NC], p2[NC], q2[NC], s2[NC], f2[NC];
+    double va[NC], vb[NC], vc[NC], vd[NC], w0[NC], wn[NC];
+    double hy[2], hq[2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        d0[c] = p0[c] = q0[c] = s0[c] = f0[c] = pw0[c] = qs0[c] = tm[c] = w0[c] = wn[c] = 0.0;
+    }
+    hy[0] = hy[1] = hq[0] = hq[1] = 0.0;
+
+    // matrix rows + f of a plane, and the y ring of that plane (x above / below the tile; the +nx entries of the line below)
+    auto load_m = [&](const int plane, double (&d)[NC], double (&p)[NC], double (&q)[NC], double (&sd)[NC], double (&fr)[NC]) {
+        const int64_t o = (int64_t)min(max(plane, -1), a.nz) * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double* m = mat(rw[c] + o);
+            d[c] = m[0]; p[c] = m[S]; q[c] = m[2 * S]; sd[c] = m[3 * S];
+            fr[c] = *fat(rw[c] + o);
+        }
+        if (wlo || whi) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                hy[r] = *xat(rwr[r] + o);
+                hq[r] = mat(rwr[r] + o)[2 * S];
+            }
+        }
+    };
+    auto load_x = [&](const int plane, double (&v)[NC]) {
+        const int64_t o = (int64_t)min(max(plane, -1), a.nz) * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = *xat(rw[c] + o);
+    };
+    // LDS images of a plane: x (with the y ring), the +1 and +nx diagonals (the latter with the line below the tile)
+    auto park = [&](const int plane, const double (&v)[NC], const double (&p)[NC], const double (&q)[NC]) {
+        const int slot = plane & 1;
+        double* const xs = sV0 + slot * V0S;
+        double* const ps = sP + slot * V1S;
+        double* const qs = sQ + slot * QS;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = lwof(c);
+            xs[iw + EX] = v[c];
+            ps[iw] = p[c];
+            qs[iw + EX] = q[c];
+        }
+        if (wlo) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { xs[lane + 64 * r] = hy[r]; qs[lane + 64 * r] = hq[r]; }
+        } else if (whi) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) xs[(EY + 1) * EX + lane + 64 * r] = hy[r];
+        }
+    };
+
+    // ---- warm-up: what step k = z0-2 finds in place ----
+    load_x(z0 - 2, va);
+    load_x(z0 - 1, vb);
+    load_x(z0, vc);
+    {
+        const int64_t o = (int64_t)min(max(z0 - 2, -1), a.nz) * a.P;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s0[c] = mat(rw[c] + o)[3 * S];        // +P entries of plane z0-2
+    }
+    load_m(z0 - 1, d1, p1, q1, s1, f1);
+    park(z0 - 1, vb, p1, q1);
+    load_m(z0, d2, p2, q2, s2, f2);
+    load_x(z0 + 1, vd);
+    __syncthreads();
+
+    for (int k = z0 - 2; k < z1; ++k) {
+        const int s1i = (k + 1) & 1;
+        const double* const x1 = sV0 + s1i * V0S + EX;
+        const double* const pim = sP + s1i * V1S;
+        const double* const qim = sQ + s1i * QS + EX;
+        double* const v1w = sV1 + s1i * V1S;
+        const double* const v1r = sV1 + (k & 1) * V1S;
+        const int64_t o1 = (int64_t)(k + 1) * a.P;
+        const bool second = k >= z0;
+        const bool keep1 = a.v1out != nullptr && k + 1 >= z0 && k + 1 < z1;
+        double pw1[NC], qs1[NC];
+        // ---- first sweep on plane k+1 ----
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = lwof(c);
+            const double xs = x1[iw - EX], xw = x1[iw - 1], xe = x1[iw + 1], xn = x1[iw + EX];
+            pw1[c] = pim[iw - 1];
+            qs1[c] = qim[iw - EX];
+            double acc = 0.0;
+            acc = fma(s0[c], va[c], acc);                               // -P
+            acc = fma(qs1[c], xs, acc);                                 // -nx
+            acc = fma(pw1[c], xw, acc);                                 // -1
+            const double diag = d1[c] != 0.0 ? d1[c] : 1.0;
+            acc = fma(d1[c], vb[c], acc);
+            acc = fma(p1[c], xe, acc);                                  // +1
+            acc = fma(q1[c], xn, acc);                                  // +nx
+            acc = fma(s1[c], vc[c], acc);                               // +P
+            const double o = vb[c] + (a.omega * (1.0 / diag)) * (f1[c] - acc);
+            const int64_t r1 = rowof(c) + o1;
+            wn[c] = (r1 >= 0 && r1 < a.nloc) ? o : 0.0;
+            v1w[iw] = wn[c];
+            if (keep1 && (inT >> c & 1u) && (r1 < a.k1_lo || r1 >= a.k1_hi)) a.v1out[r1] = wn[c];
+        }
+        // ---- second sweep on plane k ----
+        if (second) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!(lineT >> c & 1u)) continue;
+                const int iw = lwof(c);
+                const double ys = v1r[iw - EX], yw = v1r[iw - 1], ye = v1r[iw + 1], yn = v1r[iw + EX];
+                double acc = tm[c];                                         // fma(s[k-1], v1[k-1], 0), taken a step ago
+                acc = fma(qs0[c], ys, acc);
+                acc = fma(pw0[c], yw, acc);
+                const double diag = d0[c] != 0.0 ? d0[c] : 1.0;
+                acc = fma(d0[c], w0[c], acc);
+                acc = fma(p0[c], ye, acc);
+                acc = fma(q0[c], yn, acc);
+                acc = fma(s0[c], wn[c], acc);
+                const double o = w0[c] + (a.omega * (1.0 / diag)) * (f0[c] - acc);
+                const int64_t r0 = rowof(c) + o1 - a.P;
+                if ((inT >> c & 1u) && r0 >= a.st_lo && r0 < a.st_hi) a.out[r0] = o;
+            }
+        }
+        // ---- park plane k+2, rotate, issue the loads of the step after the next ----
+        park(k + 2, vc, p2, q2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            tm[c] = fma(s0[c], w0[c], 0.0);
+            d0[c] = d1[c]; p0[c] = p1[c]; q0[c] = q1[c]; s0[c] = s1[c]; f0[c] = f1[c]; pw0[c] = pw1[c]; qs0[c] = qs1[c];
+            d1[c] = d2[c]; p1[c] = p2[c]; q1[c] = q2[c]; s1[c] = s2[c]; f1[c] = f2[c];
+            w0[c] = wn[c];
+            va[c] = vb[c]; vb[c] = vc[c]; vc[c] = vd[c];
+            asm volatile("" : "+v"(d1[c]));
+            asm volatile("" : "+v"(p1[c]));
+            asm volatile("" : "+v"(q1[c]));
+            asm volatile("" : "+v"(s1[c]));
+            asm volatile("" : "+v"(f1[c]));
+            asm volatile("" : "+v"(vc[c]));
+        }
+        load_m(k + 3, d2, p2, q2, s2, f2);
+        load_x(k + 4, vd);
+        __syncthreads();
+    }
+}
+
+template <int R, int NW, int LPW>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2p(J2Args a) {
+    j2p_body<R, NW, LPW>(a);
+}
+
+template <int R, int NW, int LPW>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2p_finest(J2Args a) {
+    j2p_body<R, NW, LPW>(a);
+}
+
 // ---- ONE sweep as a plane march on class-coded rows (residual, single Jacobi sweeps, Gauss-Seidel colours) -------
 // The slice kernels (sdia_cls_body) read a row's six x neighbours as unaligned 16-byte loads through L1; here the
 // pipeline of the pair pass is used for one sweep: a tile of 126 x EY result cells (+ the x ring inside the tile's

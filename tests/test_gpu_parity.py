@@ -1061,7 +1061,8 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    variants = [dict(fuse_sweeps=0, fuse_small=0), dict(), dict(fuse_sweeps=0), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0), dict(fuse_shape=0), dict(fuse_shape=3), dict(fuse_shape=2, fuse_segments=2),
+    variants = [dict(fuse_sweeps=0, fuse_small=0), dict(), dict(fuse_sweeps=0), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0), dict(fuse_classes=0, fuse_plain_shape=1), dict(fuse_classes=0, fuse_plain_shape=2, fuse_segments=3),
+                dict(fuse_classes=0, fuse_plain=1), dict(fuse_shape=0), dict(fuse_shape=3), dict(fuse_shape=2, fuse_segments=2),
                 dict(fuse_segments=5, fuse_nontemporal=1, fuse_classes=0), dict(rows_per_lane=1),
                 dict(rows_per_lane=4, fuse_segments=2), dict(rows_per_lane=1, row_classes=0)]
     for kw in variants:

@@ -1,12 +1,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
-import numpy as np, time
-with DeviceHierarchy.synthetic_p2(3, 2, 5, c=8, mu1=2, mu2=2, omega=1.0) as dev:
-    dev.set_prolongation("p2")
-    for restr in ("direct", "table"):
-        dev.set_params(2, 2, 1.0, smoother="mcgs", restriction=restr)
-        dev.zero_vector(5, "v")
-        res = dev.vcycle(5, 8, residuals=True)
-        dev.sync(); t0 = time.perf_counter(); dev.vcycle(5, 4); dev.sync(); dt = (time.perf_counter() - t0) / 4
-        print(restr, "257^3 lattice V(2,2) mcgs residuals", " ".join("%.3e" % r for r in res), "| %.1f ms per cycle" % (dt * 1e3), flush=True)
+with DeviceHierarchy.synthetic(3, 2, 7, c=8, mu1=2, mu2=2) as dev:
+    dev.set_tuning("fuse_classes", 0)
+    for plain, shape, seg in ((1, 1, 0), (2, 1, 0), (2, 2, 0), (2, 4, 0), (2, 4, 8), (2, 4, 16), (2, 1, 8), (2, 2, 8)):
+        dev.set_tuning("fuse_plain", plain); dev.set_tuning("fuse_shape", shape); dev.set_tuning("fuse_segments", seg)
+        print("plain", plain, "shape", shape, "seg", seg, "%.3f ms per pair" % dev.time_kernel("jacobi2!", 7, 6), flush=True)
