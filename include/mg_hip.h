@@ -188,6 +188,12 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "require_diagonal"   0 accepts operators without a diagonal, e.g. D^-1 R for mg_smooth_split (1)
  *     "halo_planes"        grid planes exchanged with each slab neighbour: 1, or 2 for stencils that reach two planes
  *                          (P2 lattice levels) (1)
+ *     "storage_ulps"       k > 0: matrix entries that agree within about k units in the last place count as equal in the
+ *                          symmetry test (the upper entry of a pair is kept) and in the row dictionary (a class holds the first
+ *                          such row seen): assemblies whose rows differ by round-off (h not a power of two, varying
+ *                          summation order) then still get the compact formats.  This PERTURBS the matrix by up to k ulps
+ *                          per entry -- below the round-off of the assembly itself for small k -- so results agree with the
+ *                          exact-storage ones to ~k * 1e-16 relative, not bit for bit.  (0: everything bit for bit)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
  *   any time:
  *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)

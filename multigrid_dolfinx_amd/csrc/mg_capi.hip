@@ -228,6 +228,7 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    int storage_qbits = 0;          // "storage_ulps": low mantissa bits ignored by the symmetry test and the row dictionary
     int use_classes = 1;            // one class byte per row where a level has <= 255 distinct rows (two-sweep pass)
     int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
     int64_t fuse_min_rows = (int64_t)1 << 24;
@@ -1788,7 +1789,7 @@ int build_row_classes(mg_context* c, Level& L) {
     a.svals = reinterpret_cast<double*>(scratch.p + tag_bytes);
     a.count = ints; a.flag = ints + 1; a.slot_class = ints + 2;
     a.hist = reinterpret_cast<unsigned*>(ints + 2 + CLS_SLOTS);
-    a.ctab = ctab; a.cls = cls; a.crows = cls_rows; a.clead = cls_lead;
+    a.ctab = ctab; a.cls = cls; a.crows = cls_rows; a.clead = cls_lead; a.qbits = c->storage_qbits;
     const dim3 grid(blocks_for(L.nloc, 256)), egrid(blocks_for(cls_rows, 256)), blk(256);
     int h[2] = {0, 0};
     std::vector<unsigned> hist(256, 0u);
@@ -1916,9 +1917,9 @@ int repack_sdia(mg_context* c, Level& L, int level) {
         HIP_TRY(hipMemsetAsync(dvals, 0, (size_t)mslices * wu_t * S * sizeof(double), c->stream));
         const dim3 grid(blocks_for(L.nloc, 256)), blk(256);
         switch (L.R) {
-            case 1: hipLaunchKernelGGL(sdia_fill<1>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<1>, grid, blk, 0, c->stream, a, d_flag); break;
-            case 2: hipLaunchKernelGGL(sdia_fill<2>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<2>, grid, blk, 0, c->stream, a, d_flag); break;
-            default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<4>, grid, blk, 0, c->stream, a, d_flag); break;
+            case 1: hipLaunchKernelGGL(sdia_fill<1>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<1>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
+            case 2: hipLaunchKernelGGL(sdia_fill<2>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<2>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
+            default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<4>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2238,6 +2239,13 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         for (auto& L : c->L)
             if (L.set) return fail("symmetric_storage must be chosen before level set-up");
         c->use_sdia = value != 0;
+    } else if (k == "storage_ulps") {
+        for (auto& L : c->L)
+            if (L.set) return fail("storage_ulps must be chosen before level set-up");
+        if (value < 0 || value > 4096) return fail("storage_ulps must be in 0..4096");
+        int q = 0;
+        while ((1ll << q) < value) ++q;
+        c->storage_qbits = value > 0 ? std::max(1, q) : 0;
     } else if (k == "row_classes") {
         for (auto& L : c->L)
             if (L.set) return fail("row_classes must be chosen before level set-up");

@@ -314,7 +314,17 @@ struct ClsArgs {
     int64_t crows, clead;
     int* flag;                      // set when a row does not match its dictionary entry
     unsigned* hist;                 // 256: rows per class
+    int qbits;                      // "storage_ulps": entries are compared after rounding away this many low mantissa bits
+                                    // (0: bit for bit); a class then stands for rows that agree to about 2^qbits ulps and
+                                    // the table holds the entries of the first such row seen
 };
+
+// an entry's bits with the lowest q mantissa bits rounded away (q = 0: the bits themselves)
+__device__ __forceinline__ unsigned long long cls_quant(unsigned long long b, int q) {
+    if (q <= 0) return b;
+    const unsigned long long half = 1ull << (q - 1);
+    return ((b + half) >> q) << q;
+}
 
 __device__ __forceinline__ unsigned long long cls_mix(unsigned long long x) {
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
@@ -341,10 +351,13 @@ __device__ __forceinline__ bool cls_zero(const unsigned long long (&b)[7]) {
     return o == 0ull;
 }
 
-__device__ __forceinline__ unsigned long long cls_hash(const unsigned long long (&b)[7]) {
+__device__ __forceinline__ unsigned long long cls_hash(const unsigned long long (&b)[7], int q) {
     unsigned long long h = 0x9e3779b97f4a7c15ull;
+    // (with a tolerance the hash looks at far fewer bits than the comparison allows to differ, so that rows a few ulps
+    //  apart almost never fall into different buckets; the comparison in cls_encode then applies the tolerance itself)
+    const int qh = q > 0 ? q + 16 : 0;
 #pragma unroll
-    for (int c = 0; c < 7; ++c) h = cls_mix(h ^ (b[c] + 0x3c6ef372fe94f82bull * (unsigned long long)(c + 1)));
+    for (int c = 0; c < 7; ++c) h = cls_mix(h ^ (cls_quant(b[c], qh) + 0x3c6ef372fe94f82bull * (unsigned long long)(c + 1)));
     return h ? h : 1ull;
 }
 
@@ -355,7 +368,7 @@ __global__ void cls_insert(ClsArgs a) {
     unsigned long long b[7];
     cls_row<S>(a, row, b);
     if (cls_zero(b)) return;                                  // class 0: the all-zero row
-    const unsigned long long h = cls_hash(b);
+    const unsigned long long h = cls_hash(b, a.qbits);
     unsigned s = (unsigned)h & (CLS_SLOTS - 1);
     for (int probe = 0; probe < CLS_SLOTS; ++probe) {
         // almost every row finds its class already there: look before touching the slot with an atomic
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(256) void cls_encode(ClsArgs a) {
             unsigned long long b[7];
             cls_row<S>(a, row, b);
             if (!cls_zero(b)) {
-                const unsigned long long h = cls_hash(b);
+                const unsigned long long h = cls_hash(b, a.qbits);
                 unsigned s = (unsigned)h & (CLS_SLOTS - 1);
                 bool found = false;
                 for (int probe = 0; probe < CLS_SLOTS; ++probe) {
@@ -415,7 +428,11 @@ __global__ __launch_bounds__(256) void cls_encode(ClsArgs a) {
                         bool same = true;
 #pragma unroll
                         for (int c = 0; c < 7; ++c)
-                            same = same && (unsigned long long)__double_as_longlong(a.svals[CLS_W * s + c]) == b[c];
+                        {
+                            const long long sv = __double_as_longlong(a.svals[CLS_W * s + c]), bv = (long long)b[c];
+                            const long long d = sv - bv;
+                            same = same && (sv == bv || (a.qbits > 0 && (sv < 0) == (bv < 0) && (d < 0 ? -d : d) <= (1ll << a.qbits)));
+                        }
                         id = a.slot_class[s];
                         found = same && id != 0;                    // hash collision / overflow: no classes
                         break;

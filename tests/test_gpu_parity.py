@@ -1188,6 +1188,46 @@ def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi
                 assert np.all(np.abs(res - want["res"]) <= 1e-13 * want["res"]), kw
 
 
+def test_storage_ulps_brings_round_off_noisy_assemblies_to_the_compact_formats():
+    """An assembly whose rows differ by round-off (h not a power of two, varying summation order) is neither bit-for-bit
+    symmetric nor repetitive: it keeps the offset-coded format.  With `storage_ulps` = k entries that agree within ~k
+    ulps count as equal in the symmetry test and the row dictionary, the level gets symmetric diagonals + row classes
+    (and with them the paired pass), and the results agree with the exact-storage ones to round-off -- by construction
+    not bit for bit: the knob perturbs the matrix by up to k ulps per entry and is off by default."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(21)
+    bag = poisson.make_hierarchy(3, 1, 3, c=5, mu1=2, mu2=2, seed=None)         # 41^3 unknowns on the finest level
+    A = bag.A_sp_dict[3][0].tocsr().copy()
+    ulp = 2.0 ** -52
+    A.data = A.data * (1.0 + ulp * rng.integers(-1, 2, A.data.size))            # every entry off by -1, 0 or +1 ulp
+    n = A.shape[0]
+    v_in = rng.standard_normal(n)
+    outs = {}
+    for ulps in (0, 8):
+        with DeviceHierarchy(3, 1, 3, c=5, storage_ulps=ulps) as dev:
+            dev.set_tuning("fuse_min_rows", 0)
+            for l in (1, 2):
+                dev.set_level(l, bag.A_sp_dict[l][0], bag.levels[l].grid_index)
+            dev.set_level(3, A, bag.levels[3].grid_index)
+            dev.set_params(4, 4, 2.0 / 3.0)
+            info = dev.level_info(3)
+            if ulps == 0:
+                assert info["symmetric_diagonals"] == 0 and info["offset_codes"] == 7 and info["row_classes"] == 0, info
+            else:
+                assert info["symmetric_diagonals"] == 4 and 2 <= info["row_classes"] <= 255, info
+                assert dev.time_kernel("jacobi2", 3, 1) > 0.0
+            dev.set_vector(3, "v", v_in)
+            dev.set_vector(3, "f", bag.b_dict[3])
+            dev.smooth(3, 6)
+            sm = dev.get_vector(3, "v")
+            dev.zero_vector(3, "v")
+            res = dev.vcycle(3, 3, residuals=True)
+            outs[ulps] = (sm, res, dev.get_vector(3, "v"))
+    assert rel_l2(outs[8][0], outs[0][0]) <= 1e-13
+    assert np.all(np.abs(outs[8][1] - outs[0][1]) <= 1e-11 * outs[0][1])
+    assert rel_l2(outs[8][2], outs[0][2]) <= 1e-12
+
+
 def test_time_kernel_reports_where_the_two_sweep_pass_is_not_used():
     """`mg_time_kernel("jacobi2")` is how bench.py finds out whether the smoother pairs sweeps on a level: an error on
     levels where it does not (2-D, too small), a duration where it does."""
