@@ -202,6 +202,10 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "lds_pad"            dynamic LDS bytes per block on large levels = occupancy cap (32768)
  *     "overlap"            halo exchange on the communication stream behind the interior sweep (1)
  *     "overlap_min_rows"   ... only on levels with at least this many owned rows (4194304)
+ *     "graph_comm"         1 = V-cycles on slabs are captured into hipGraphs too, RCCL exchanges included (the calls are
+ *                          stream operations on both streams of the overlapped sweeps); every rank must set it alike.
+ *                          Needs the RCCL transport (mg_comm_init_rccl).  (0: validated against the in-process stand-in of
+ *                          tests/fake_rccl only, not against RCCL on a multi-GPU node)
  *     "fuse_restrict"      residual evaluated at the coarse nodes only when injecting (1)
  *     "fuse_sweeps"        Jacobi sweeps in pairs, two per pass over the matrix, on 3-D 7-point levels in
  *                          symmetric diagonal storage (1); bit-identical to single sweeps
@@ -286,6 +290,11 @@ int mg_restrict(mg_handle h, int level, int kind);
 int mg_prolong(mg_handle h, int level, int add);
 int mg_coarse_solve(mg_handle h, int* iterations, double* rel_residual);
 int mg_vcycle(mg_handle h, int level, int ncycles, double* resid_l2);
+/* Builds and allocates now what the first V-cycle from `level` would build lazily (direct coarsest solve, colouring checks,
+ * work vectors) and waits for it: the cycles that follow only enqueue work.  Optional; useful before timing, and on slabs
+ * with "graph_comm" so that every rank enters its first (captured) cycle without set-up work of its own in between.  No
+ * reference counterpart. */
+int mg_prepare_cycle(mg_handle h, int level);
 int mg_norm2(mg_handle h, int level, int which, double* out);
 /* out = x^T A x for the level's matrix (one tile SpMV fused with the dot product).  With a P1 mass
  * matrix handed over as the level's matrix this is the square of the reference's L2(Omega) norm

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mg_prolong": [_H, C.c_int, C.c_int],
     "mg_coarse_solve": [_H, _ip, _dp],
     "mg_vcycle": [_H, C.c_int, C.c_int, C.c_void_p],
+    "mg_prepare_cycle": [_H, C.c_int],
     "mg_norm2": [_H, C.c_int, C.c_int, _dp],
     "mg_quadratic_form": [_H, C.c_int, C.c_int, _dp],
     "mg_set_rhs_true": [_H, C.c_int, C.c_void_p],

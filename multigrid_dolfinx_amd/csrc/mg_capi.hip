@@ -223,6 +223,7 @@ struct mg_context {
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
     int use_graph = 1;              // replay whole V-cycles as hipGraphs (single GPU, direct coarsest solve)
+    int graph_comm = 0;             // ... on slabs too: the RCCL exchanges are captured with the kernels (opt-in)
     uint64_t epoch = 1;             // bumped by every call that changes what a V-cycle launches
     std::vector<CycleGraph> graphs;
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
@@ -1641,14 +1642,28 @@ void drop_graphs(mg_context* c) {
 // levels then cost a kernel boundary instead of a host launch each.  The Jacobi ping-pong swaps the
 // MG_VEC_V buffers mu1+mu2 times per level; the captured pointer state is part of the cache key and the
 // swaps are re-applied on the host after a replay.
-int vcycle_graphed(mg_context* c, int level) {
+// Everything a V-cycle from `level` builds or allocates on first use (the direct coarsest solve and its validation, the
+// colouring checks, the parked-sweep and error vectors): afterwards a cycle -- and its capture -- only enqueues work.
+int prepare_cycle(mg_context* c, int level) {
     if (!c->direct.tried) { MG_TRY(build_direct(c)); MG_TRY(validate_direct(c)); }
     if (c->smoother == MG_SMOOTH_MCGS)                   // (the check synchronises: not inside a capture)
         for (int l = 1; l <= level; ++l)
             if (c->L[l].mc_ok < 0 && !c->L[l].flat) MG_TRY(check_coloring(c, c->L[l]));
-    if (!c->use_graph || c->comm.active() || level == 0 || !c->direct.ok) return vcycle(c, level);
+    if (c->comm.active())
+        for (int l = 1; l <= level; ++l)
+            if (!c->L[l].replicated) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].sw));
     if (c->keep_err)
         for (int l = 1; l <= level; ++l) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].err));
+    return 0;
+}
+
+int vcycle_graphed(mg_context* c, int level) {
+    MG_TRY(prepare_cycle(c, level));
+    // Slabs: RCCL's point-to-point calls are stream operations and are captured with the kernels (both streams of the
+    // overlapped sweeps join the capture through their events).  Opt-in ("graph_comm"): every rank must take the same
+    // decision, and this build could only be validated against the in-process stand-in (tests/fake_rccl).
+    const bool slabs = c->comm.active();
+    if (!c->use_graph || level == 0 || !c->direct.ok || (slabs && !(c->graph_comm && c->comm.nccl))) return vcycle(c, level);
     std::vector<double*> pre(level + 1);
     for (int l = 0; l <= level; ++l) pre[l] = c->L[l].v.raw;
     for (auto& g : c->graphs) {
@@ -2221,6 +2236,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "graph") {
         c->use_graph = value != 0;
+        return 0;
+    }
+    if (k == "graph_comm") {
+        c->graph_comm = value != 0;
         return 0;
     }
     if (k == "rows_per_lane") {
@@ -2973,6 +2992,18 @@ int mg_counters(mg_handle c, int64_t* uploads, int64_t* downloads, int64_t* grap
     if (downloads) *downloads = c->downloads;
     if (graph_replays) *graph_replays = c->graph_replays;
     if (graphs_cached) *graphs_cached = (int)c->graphs.size();
+    return 0;
+}
+
+int mg_prepare_cycle(mg_handle c, int level) {
+    MG_TRY(check_level(c, level));
+    for (int l = 0; l <= level; ++l) {
+        MG_TRY(need_matrix(c, l));
+        if (level > 0) MG_TRY(need_grid(c, l));
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    MG_TRY(prepare_cycle(c, level));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -395,6 +395,10 @@ class DeviceHierarchy:
     def prolong(self, level: int, add: bool = True):
         check(self._lib.mg_prolong(self._h, self._idx(level), 1 if add else 0))
 
+    def prepare_cycle(self, level):
+        """Build now what the first V-cycle from `level` would build lazily (mg_prepare_cycle)."""
+        check(self._lib.mg_prepare_cycle(self._h, self._idx(level)))
+
     def coarse_solve(self):
         it, rel = C.c_int(), C.c_double()
         check(self._lib.mg_coarse_solve(self._h, C.byref(it), C.byref(rel)))

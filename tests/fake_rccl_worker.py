@@ -24,6 +24,15 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
     uid = buf.raw
     results, errors = [None] * world, []
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("MG_TEST_TUNE", "").split(",") if kv}
+    bar = threading.Barrier(world)
+
+    def phase(h):
+        # The capturable stand-in's receives spin ON THE DEVICE until the peer's send is enqueued, and calls that wait for
+        # the whole device (hipFree in level set-up, graph destruction) wait for those spins too -- threads of one process
+        # share the device, ranks of a real job do not.  So the ranks line up between phases: nobody frees memory while a
+        # peer already waits for a message this rank has not enqueued yet.
+        h.sync()
+        bar.wait(timeout=200)
 
     def rank_main(rank):
         try:
@@ -34,24 +43,35 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
             h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, **tune)
             info = h.level_info(hi)
             assert not info["replicated"] and info["n_local"] < info["n_global"]
+            h.prepare_cycle(hi)
+            phase(h)
             h.zero_vector(hi, "v")
             res = h.vcycle(hi, 3, residuals=True)
+            phase(h)
             full = h.get_vector(hi, "v", gather=True)
-            h.set_params(mu, mu, 2 / 3, restriction="full_weighting")
+            h.set_params(mu, mu, 2 / 3, restriction="full_weighting")      # (drops the graphs: before the line-up)
+            phase(h)
             h.zero_vector(hi, "v")
             h.vcycle(hi, 1)
+            phase(h)
             fw = h.get_vector(hi, "v", gather=True)
-            h.set_params(mu, mu, 1.0, smoother="rbgs")
+            h.set_params(mu, mu, 1.0, smoother="rbgs")      # (drops the graphs: before the line-up)
+            phase(h)
             h.zero_vector(hi, "v")
             h.vcycle(hi, 1)
+            phase(h)
             gs = h.get_vector(hi, "v", gather=True)
             nrm = h.norm2(hi, "v")
+            if tune.get("graph_comm"):                               # the cycles really were captured and replayed
+                assert h.counters()["graph_replays"] >= 2, h.counters()
             results[rank] = (full, res, fw, gs, nrm)
+            phase(h)
             h.close()
         except Exception as exc:                                     # noqa: BLE001
             import traceback
             traceback.print_exc()
             errors.append(exc)
+            bar.abort()
 
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads:
@@ -60,6 +80,10 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
         t.join(timeout=240)
     assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
     assert not errors, errors
+    if "graph" in os.path.basename(os.environ["MG_RCCL_LIBRARY"]):
+        fake = C.CDLL(os.environ["MG_RCCL_LIBRARY"])
+        fake.fake_rccl_graph_timeouts.restype = C.c_longlong
+        assert fake.fake_rccl_graph_timeouts() == 0, "a device-side handshake of the stand-in timed out"
 
     with DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, **tune) as ser:
         ser.zero_vector(hi, "v")

@@ -4,6 +4,10 @@ stand-in, so the GPU does the same total sweep work as a single handle plus the 
 the ratio of the two wall times bounds the non-link overhead of the decomposition.
 
     MG_RCCL_LIBRARY=tests/fake_rccl/libfake_rccl.so python tools/slab_overhead_probe.py [world] [finest] [mu]
+
+With the capturable stand-in and the opt-in graph path (one hipGraphLaunch per cycle and rank instead of ~4800 calls):
+
+    GPU_MAX_HW_QUEUES=24 MG_TEST_TUNE=graph_comm=1 MG_RCCL_LIBRARY=tests/fake_rccl/libfake_rccl_graph.so python tools/...
 """
 import ctypes as C
 import os
@@ -18,6 +22,7 @@ from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy          # noqa: E40
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 mu = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("MG_TEST_TUNE", "").split(",") if kv}
 
 with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=mu, mu2=mu) as ser:
     ser.zero_vector(hi, "v")
@@ -33,21 +38,25 @@ buf = C.create_string_buffer(128)
 _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
 uid = buf.raw
 start = threading.Barrier(world)
-times, errors = [0.0] * world, []
+times, replays, errors = [0.0] * world, [0] * world, []
 
 
 def rank_main(rank):
     try:
         h = DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=mu, mu2=mu,
-                                      comm=lambda hh: hh.set_comm_rccl(rank, world, uid, replicate_below=1 << 22))
+                                      comm=lambda hh: hh.set_comm_rccl(rank, world, uid, replicate_below=1 << 22), **tune)
+        h.prepare_cycle(hi)
+        h.sync()
+        start.wait()
         h.zero_vector(hi, "v")
-        h.vcycle(hi, 1)
+        h.vcycle(hi, 2 if tune.get("graph_comm") else 1)             # (the first graphed cycle is the capture)
         h.sync()
         start.wait()
         t0 = time.perf_counter()
         h.vcycle(hi, 2)
         h.sync()
         times[rank] = (time.perf_counter() - t0) / 2
+        replays[rank] = h.counters()["graph_replays"]
         start.wait()
         h.close()
     except Exception as exc:                                     # noqa: BLE001
@@ -64,4 +73,9 @@ for t in threads:
     t.join(timeout=1100)
 assert not errors, errors
 t_slabs = max(times)
-print(f"{world} slabs on one GPU: {t_slabs * 1e3:.1f} ms per cycle = {t_slabs / t_single:.3f} x the single handle")
+print(f"{world} slabs on one GPU: {t_slabs * 1e3:.1f} ms per cycle = {t_slabs / t_single:.3f} x the single handle"
+      f" (graph replays per rank: {min(replays)}, tuning {tune})")
+if "graph" in os.path.basename(os.environ.get("MG_RCCL_LIBRARY", "")):
+    fake = C.CDLL(os.environ["MG_RCCL_LIBRARY"])
+    fake.fake_rccl_graph_timeouts.restype = C.c_longlong
+    print("handshake time-outs:", fake.fake_rccl_graph_timeouts())
