@@ -223,6 +223,7 @@ struct mg_context {
     int pcg_parts = 0, pcg_parts_a = 0;
     int pcg_predict = 0;
     int use_graph = 1;              // replay whole V-cycles as hipGraphs (single GPU, direct coarsest solve)
+    int comm_priority = 1;          // communication stream created with the highest priority (MG_COMM_PRIORITY=0: lowest)
     int graph_comm = 0;             // ... on slabs too: the RCCL exchanges are captured with the kernels (opt-in)
     uint64_t epoch = 1;             // bumped by every call that changes what a V-cycle launches
     std::vector<CycleGraph> graphs;
@@ -593,7 +594,8 @@ bool sweep1c_ok(const mg_context* c, const Level& L);
 // out = op(A, x) over all owned slices of the level
 int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
                double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr,
-               int64_t slice0 = 0, int64_t slice_count = -1, int color = 0) {
+               int64_t slice0 = 0, int64_t slice_count = -1, int color = 0, int64_t split = 0, int64_t gap = 0) {
+    // (gap > 0: the slice_count slices are [slice0, slice0 + split) and [slice0 + split + gap, ...) -- two ranges, one launch)
     if (slice_count < 0) slice_count = L.nslices - slice0;
     if (slice_count == 0) return 0;
     // whole large 3-D levels with row classes: one sweep as a plane march (mg_jacobi2.hip.h, sdia_sweep1c)
@@ -602,7 +604,7 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
     EllArgs a{};
     a.vals = L.vals; a.cols = L.cols; a.x = x_base; a.f = f_rows; a.dinv = L.dinv; a.out = out_rows;
     a.partials = partials; a.done_flag = done; a.nloc = L.nloc; a.lead = L.g.lead;
-    a.slice0 = slice0; a.nslices = slice_count; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
+    a.slice0 = slice0; a.nslices = slice_count; a.split = split; a.gap = gap; a.omega = c->omega; a.W = L.W; a.chunk = c->chunk;
     a.codes = L.codes; a.offsets = L.offsets; a.ntable = L.ntable; a.dcode = L.dcode;
     a.color = color; a.color_kind = c->smoother == MG_SMOOTH_MCGS ? COLOR_LATTICE9 : COLOR_PARITY;
     a.grow0 = L.row0; a.gnx = L.g.nx; a.gny = L.g.ny;
@@ -1237,25 +1239,29 @@ int smooth(mg_context* c, int level, int nw) {
             const int64_t st_lo = lo ? lo_end * S : 0, st_hi = hi ? hi_begin * S : INT64_MAX;
             auto boundary_chain = [&](hipStream_t stream) -> int {
                 MG_TRY(exchange_halo(c, L, L.sw, stream));
-                if (lo) MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
-                if (hi)
+                // (the first and the last slices in one launch where the slab has both neighbours)
+                if (lo && hi)
+                    MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0,
+                                      lo_end + L.nslices - hi_begin, 0, lo_end, hi_begin - lo_end));
+                else if (lo)
+                    MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
+                else if (hi)
                     MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.sw.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
                                       L.nslices - hi_begin));
                 MG_TRY(exchange_halo(c, L, L.v2, stream));
                 return 0;
             };
             if (overlap && plan.nseg >= 3) {
-                // the two boundary segments and everything that waits for the neighbours run on the communication
-                // stream, the interior segments beside them on the main stream; the pair ends when both have
+                // The two boundary segments first, alone on the GPU (launched beside the interior they are dispatched
+                // AFTER it -- the event hop delays them -- and then finish late: measured, profiles/r02_slab_rank_*),
+                // then the interior segments on the main stream while everything that waits for the neighbours runs
+                // on the (high-priority) communication stream; the pair ends when both have.
+                MG_TRY(launch_jacobi2(c, L, plan, 0, plan.nseg - 1, 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
                 HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
-                std::swap(c->stream, c->comm_stream);
-                int rc = launch_jacobi2(c, L, plan, 0, plan.nseg - 1, 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows);
-                std::swap(c->stream, c->comm_stream);
-                MG_TRY(rc);
                 MG_TRY(launch_jacobi2(c, L, plan, 1, 1, plan.nseg - 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
                 std::swap(c->stream, c->comm_stream);
-                rc = boundary_chain(c->stream);
+                const int rc = boundary_chain(c->stream);
                 std::swap(c->stream, c->comm_stream);
                 MG_TRY(rc);
                 HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
@@ -1275,9 +1281,8 @@ int smooth(mg_context* c, int level, int nw) {
             continue;
         }
         // boundary planes first, then their exchange on the communication stream while the interior runs
-        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0, lo_end));
-        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, hi_begin,
-                          L.nslices - hi_begin));
+        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.v2.rows, nullptr, nullptr, nullptr, 0,
+                          lo_end + L.nslices - hi_begin, 0, lo_end, hi_begin - lo_end));
         HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
         MG_TRY(exchange_halo(c, L, L.v2, c->comm_stream));
@@ -2023,13 +2028,20 @@ int mg_create(int n_levels, int dim, int device, mg_handle* out) {
     if (device < 0 || device >= ndev) return fail("device index out of range");
     HIP_TRY(hipSetDevice(device));
     mg_context* c = new mg_context();
+    if (const char* e = std::getenv("MG_COMM_PRIORITY")) c->comm_priority = std::atoi(e) != 0;      // experiments only
     c->dim = dim;
     c->nlev = n_levels;
     c->device = device;
     c->L.resize(n_levels);
     HIP_TRY(hipGetDeviceProperties(&c->prop, device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    {
+        // the communication stream outranks the main one: when a slab sweep is split, the boundary pieces (whose results
+        // the neighbours wait for) are dispatched before the interior launched beside them, not interleaved with it
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, c->comm_priority ? greatest : least));
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
     MG_TRY(dev_alloc(c, &c->partials, 2 * kMaxParts));

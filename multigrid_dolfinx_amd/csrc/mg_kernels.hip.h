@@ -136,6 +136,9 @@ struct EllArgs {
     int64_t nloc;           // owned rows
     int64_t lead;           // x[lead + row] is the row's own entry
     int64_t slice0, nslices;  // slices [slice0, slice0 + nslices) are processed
+    // ... in two ranges when gap > 0: the slices from the split-th on lie `gap` slices further up (a slab's first and
+    // last slices in one launch)
+    int64_t split, gap;
     double omega;
     int W;                  // runtime width (used when the template width is 0)
     unsigned chunk;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
         // a colour fixes the parity of the line (j, k) except for the two vertex colours, which fix (even, even): a slice
         // (64 R consecutive rows: part of one or two lines when a line is longer) none of whose lines can hold the colour
         // is skipped before it streams its part of the matrix
-        const int64_t g0 = (a.slice0 + sl) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
+        const int64_t g0 = (a.slice0 + sl + (sl >= a.split ? a.gap : 0)) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
         const int64_t l0 = g0 / a.gnx, l1 = g1 / a.gnx;
         const int want = (a.color == 8 ? 0 : a.color) >> 1;              // bits (j & 1) | (k & 1) << 1
         bool any = false;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply_coded(EllArgs a) {
         if (!any) sl = a.nslices;
     }
     if (sl < a.nslices) {
-        const int64_t slice = a.slice0 + sl;
+        const int64_t slice = a.slice0 + sl + (sl >= a.split ? a.gap : 0);
         const int W = WT > 0 ? WT : a.W;                       // WT == 0: run-time width (wide stencils)
         const int ncw = WT > 0 ? CW : (a.W + 7) / 8;
         const size_t base = (size_t)slice * (size_t)W * (WAVE * R) + (size_t)lane * R;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void ell_cls_apply(EllArgs a, const unsigned
     int64_t sl = (int64_t)swizzle_block(blockIdx.x, gridDim.x, a.chunk) * WAVES_PER_BLOCK + wave;
     double dot = 0.0;
     if (MODE == MODE_GS && a.color_kind == COLOR_LATTICE9 && sl < a.nslices) {
-        const int64_t g0 = (a.slice0 + sl) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
+        const int64_t g0 = (a.slice0 + sl + (sl >= a.split ? a.gap : 0)) * (WAVE * R) + a.grow0, g1 = g0 + WAVE * R - 1;
         const int64_t l0 = g0 / a.gnx, l1 = g1 / a.gnx;
         const int want = (a.color == 8 ? 0 : a.color) >> 1;
         bool any = l1 - l0 >= 4;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void ell_cls_apply(EllArgs a, const unsigned
         if (!any) sl = a.nslices;
     }
     if (sl < a.nslices) {
-        const int64_t slice = a.slice0 + sl;
+        const int64_t slice = a.slice0 + sl + (sl >= a.split ? a.gap : 0);
         const int64_t row = slice * (WAVE * R) + (int64_t)lane * R;
         const double* xrow = a.x + a.lead + row;
         double acc[R], diag[R], xr[R];
@@ -551,7 +554,7 @@ __device__ __forceinline__ void sdia_body(const EllArgs& a) {
     }
     double dot = 0.0;
     if (sl < a.nslices) {
-        const int64_t slice = a.slice0 + sl;
+        const int64_t slice = a.slice0 + sl + (sl >= a.split ? a.gap : 0);
         const int64_t row = slice * S + (int64_t)lane * R;
         const int64_t m = row + a.mlead;                               // matrix row of r = 0 (m % S == lane*R)
         const size_t base = (size_t)(m / S) * WU * S + (size_t)lane * R;
@@ -645,7 +648,7 @@ __device__ __forceinline__ void sdia_cls_body(const EllArgs& a) {
             sl = (int64_t)swizzle_block(vb, a.nvirt, a.chunk) * WAVES_PER_BLOCK + wave;
         }
         const bool active = sl < a.nslices;
-        const int64_t row = (a.slice0 + (active ? sl : 0)) * S + (int64_t)lane * R;
+        const int64_t row = (a.slice0 + (active ? sl + (sl >= a.split ? a.gap : 0) : 0)) * S + (int64_t)lane * R;
         const double* xrow = a.x + a.lead + row;
         int own[R];
         DVecU<R> xl[WU], xu[WU];
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void ell_apply(EllArgs a) {
     const int64_t sl = (int64_t)b * WAVES_PER_BLOCK + wave;
     double dot = 0.0;
     if (sl < a.nslices) {
-        const int64_t slice = a.slice0 + sl;
+        const int64_t slice = a.slice0 + sl + (sl >= a.split ? a.gap : 0);
         const int W = WT > 0 ? WT : a.W;
         const size_t base = (size_t)slice * (size_t)W * (WAVE * R) + (size_t)lane * R;
         const int64_t row = slice * (WAVE * R) + (int64_t)lane * R;

@@ -1,6 +1,7 @@
 // TEST / MEASUREMENT INFRASTRUCTURE: a one-rank "loopback" stand-in for the RCCL entry points libmg_hip.so uses.  It lets
 // ONE rank of an N-slab decomposition run alone on a GPU: communicator set-up never waits for peers, a grouped
-// ncclRecv from a neighbour is served by an asynchronous device copy of what the same group ncclSends to that neighbour
+// ncclRecv from a neighbour is served by a device copy (ONE kernel per group, as RCCL fuses a group's sends and receives
+// into one launch) of what the same group ncclSends to that neighbour
 // (same size on a slab: the planes are mirrored, so the values are wrong but the work, the stream ordering and the bytes
 // written are those of a real exchange minus the link), broadcasts from other roots and all-reduces leave the buffer as it
 // is.  Every operation is a stream operation, so the cycle can also be captured ("graph_comm").  Used by
@@ -20,18 +21,36 @@ thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
 size_t type_size(ncclDataType_t t) { return t == ncclDouble ? 8 : (t == ncclFloat ? 4 : 1); }
 
+struct Copies { const double* src[4]; double* dst[4]; unsigned long long n[4]; int count; };
+
+// a few workgroups only, like a point-to-point RCCL kernel (blockIdx.y = the copy)
+__global__ void k_group_copy(Copies c) {
+    const int k = blockIdx.y;
+    const double* s = c.src[k];
+    double* d = c.dst[k];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n[k]; i += (unsigned long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
 ncclResult_t flush() {
-    ncclResult_t rc = ncclSuccess;
+    Copies c{};
+    hipStream_t stream = nullptr;
     for (auto& r : t_ops) {
         if (r.is_send) continue;
         for (auto& s : t_ops)
-            if (s.is_send && s.peer == r.peer && s.bytes == r.bytes) {
-                if (hipMemcpyAsync(r.rbuf, s.sbuf, r.bytes, hipMemcpyDeviceToDevice, r.stream) != hipSuccess) rc = ncclUnhandledCudaError;
+            if (s.is_send && s.peer == r.peer && s.bytes == r.bytes && c.count < 4) {
+                c.src[c.count] = static_cast<const double*>(s.sbuf);
+                c.dst[c.count] = static_cast<double*>(r.rbuf);
+                c.n[c.count] = r.bytes / 8;
+                ++c.count;
+                stream = r.stream;
                 break;
             }
     }
     t_ops.clear();
-    return rc;
+    if (c.count == 0) return ncclSuccess;
+    hipLaunchKernelGGL(k_group_copy, dim3(16, c.count), dim3(512), 0, stream, c);
+    return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 }  // namespace
 

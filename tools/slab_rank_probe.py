@@ -1,5 +1,5 @@
 """What does ONE slab's GPU do per V-cycle?  A single rank of a `world`-slab decomposition runs alone on the GPU through
-the loopback RCCL stand-in (tests/fake_rccl/fake_rccl_loopback.cpp: exchanges become device copies of the rank's own
+the loopback RCCL stand-in (tests/fake_rccl/fake_rccl_loopback.hip: exchanges become device copies of the rank's own
 planes, no peers), so its wall time per cycle is the decomposition's compute + launch cost on one GPU of the node -- boundary /
 interior split launches, events, the 1/world-size kernels, the replicated coarse levels -- without the link time and
 without the artefacts of `world` ranks time-slicing one GPU (tools/slab_overhead_probe.py).  The bound on the speed-up
