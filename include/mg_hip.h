@@ -238,6 +238,10 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "cls_blocks_per_cu"  persistent blocks per CU of the one-sweep class kernels (4)
  *     "coarse_direct"      exact block-tridiagonal coarsest solve, 0 = PCG (1)
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
+ *     "lattice_march"      wide lattice stencils (3-D P2 levels with stencil classes) as a plane march with five planes of x in
+ *                          LDS instead of gathers from global memory (1); bit-identical either way
+ *     "lattice_march_min_rows"  ... only on levels with at least this many owned rows (262144)
+ *     "lattice_segments"   plane segments per tile of that march, 0 = chosen from the tile count (0)
  *     "graph"              replay V-cycles as hipGraphs on a single GPU (1)
  * None of them changes results beyond round-off; the tests pin which ones are bit-for-bit neutral. */
 int mg_set_tuning(mg_handle h, const char* key, int64_t value);

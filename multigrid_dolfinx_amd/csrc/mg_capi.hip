@@ -5,6 +5,7 @@
 #include "mg_kernels.hip.h"
 #include "mg_direct.hip.h"
 #include "mg_jacobi2.hip.h"
+#include "mg_lattice.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -152,6 +153,11 @@ struct Level {
     double* s_val = nullptr;
     int* s_cnt = nullptr;
     int nscls = 0;
+    // ... and what the plane march of wide lattice stencils needs (mg_lattice.hip.h): entries as (di, dj, dk), the
+    // most frequent classes
+    int* s_pack = nullptr;
+    int lm_ntop = 0;
+    int lm_top[LM_K] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cmain = 0;                          // the most frequent class and its entries (passed to the kernels by value)
     double cm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t cls_lead = 0, cls_rows = 0;     // cls[row + cls_lead], zero padding of cls_lead entries on both sides
@@ -224,6 +230,9 @@ struct mg_context {
     int pcg_predict = 0;
     int use_graph = 1;              // replay whole V-cycles as hipGraphs (single GPU, direct coarsest solve)
     int comm_priority = 1;          // communication stream created with the highest priority (MG_COMM_PRIORITY=0: lowest)
+    int lattice_march = 1;          // wide lattice stencils (P2 levels) as a plane march with x in LDS (mg_lattice.hip.h)
+    int64_t lattice_march_min_rows = 1 << 18;
+    int lattice_segments = 0;       // plane segments per tile of that march, 0 = chosen from the tile count
     int graph_comm = 0;             // ... on slabs too: the RCCL exchanges are captured with the kernels (opt-in)
     uint64_t epoch = 1;             // bumped by every call that changes what a V-cycle launches
     std::vector<CycleGraph> graphs;
@@ -439,7 +448,8 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.s_off, (size_t)256 * L.W);
     dev_free(c, L.s_val, (size_t)256 * L.W);
     dev_free(c, L.s_cnt, 256);
-    L.nscls = 0;
+    dev_free(c, L.s_pack, (size_t)256 * L.W);
+    L.nscls = 0; L.lm_ntop = 0;
     L.coded = false;
     L.rb_ok = false;
     L.mc_ok = -1;
@@ -591,6 +601,50 @@ int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows
                    int color);
 bool sweep1c_ok(const mg_context* c, const Level& L);
 
+int allow_large_lds(mg_context* c, const void* kernel, size_t bytes);
+
+// Plane march of wide lattice stencils (mg_lattice.hip.h): 3-D grid levels with stencil classes whose entries reach at
+// most two cells / lines / planes (prepare_lat_march found them decomposable).
+bool lat_march_ok(const mg_context* c, const Level& L) {
+    return c->lattice_march && L.scls && L.s_pack && L.lm_ntop > 0 && !L.flat && L.g.ny >= LM_TJ && L.g.nx >= LM_TI / 2 &&
+           L.nloc >= c->lattice_march_min_rows;
+}
+
+int launch_lat_march(mg_context* c, const Level& L, int mode, const double* x_rows, const double* f_rows, double* out_rows,
+                     int color) {
+    LatArgs a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.cls = L.scls; a.s_pack = L.s_pack; a.s_val = L.s_val; a.s_cnt = L.s_cnt;
+    a.W = L.W; a.WP = (L.W + 3) / 4 * 4 + 4; a.ntop = L.lm_ntop;
+    for (int t = 0; t < LM_K; ++t) a.top[t] = L.lm_top[t];
+    a.nloc = L.nloc; a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.P = L.g.plane;
+    a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.kg0 = (int)(L.row0 / L.g.plane);
+    a.color = color; a.omega = c->omega;
+    a.ntx = (L.g.nx + LM_TI - 1) / LM_TI; a.nty = (L.g.ny + LM_TJ - 1) / LM_TJ;
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    // two workgroups per CU resident; a few rounds of them, each segment paying five planes of warm-up
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    // about 6.5 rounds of the 2 * cus resident workgroups (measured on the 513^3 lattice: 5 .. 12 segments per tile within
+    // 4 %, the finer cuts ahead -- the rounds are not rigid), segments of at least 16 planes (5 planes of warm-up each)
+    int nseg = c->lattice_segments > 0 ? c->lattice_segments : (int)std::max<int64_t>(1, (13 * cus + ntile - 1) / ntile);
+    nseg = std::max(1, std::min(nseg, std::max(1, L.g.nk / 16)));
+    a.seglen = (L.g.nk + nseg - 1) / nseg;
+    nseg = (L.g.nk + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    a.xcd_chunk = 16;
+    const int64_t group = 8 * (int64_t)a.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    const size_t lds = lm_lds_bytes(L.W);
+    void (*kern)(LatArgs) = mode == MODE_RESIDUAL ? lat_march<MODE_RESIDUAL> : mode == MODE_GS ? lat_march<MODE_GS> : lat_march<MODE_JACOBI>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)80 * 1024));
+    if (lds > (size_t)80 * 1024) return fail("lattice march: class tables too wide");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LM_THREADS), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // out = op(A, x) over all owned slices of the level
 int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* x_base, const double* f_rows,
                double* out_rows, double* partials, const int* done, unsigned* grid_out = nullptr,
@@ -664,6 +718,9 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         return 0;
     }
     if (L.coded && L.scls && c->class_sweeps) {
+        // whole 3-D lattice levels: plane march with x in LDS (mg_lattice.hip.h)
+        if (!dot && !done && mode != MODE_SPMV && slice0 == 0 && slice_count == L.nslices && gap == 0 && lat_march_ok(c, L))
+            return launch_lat_march(c, L, mode, x_base + L.g.lead, f_rows, out_rows, color);
         // wide rows through their stencil classes: 25 bytes per row instead of the stored row (ell_cls_apply)
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
@@ -1439,10 +1496,18 @@ int build_direct(mg_context* c) {
     if (!c->use_direct || L.flat || L.g.lead != 0) return 0;
     const int64_t plane = L.g.plane;
     const int nz = L.g.nz;
-    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(nz, (512 + plane - 1) / plane));
+    // planes per block: at least ~512 rows, and at least as many planes as the stencil reaches (P2 rows reach two: the
+    // blocks must couple to their neighbours only)
+    int64_t reach = 1;
+    if (L.coded && L.ntable > 0) {
+        std::vector<int> offs(256);
+        HIP_TRY(hipMemcpy(offs.data(), L.offsets, 256 * sizeof(int), hipMemcpyDeviceToHost));
+        for (int t = 0; t < L.ntable; ++t) reach = std::max<int64_t>(reach, (std::llabs((long long)offs[t]) + plane / 2) / plane);
+    }
+    const int64_t G = std::max<int64_t>(reach, std::min<int64_t>(nz, (512 + plane - 1) / plane));
     const int64_t p = G * plane;
     const int64_t nb = (nz + G - 1) / G;
-    if (p > 2048 || nb * p * p * 8 > ((int64_t)3 << 29)) return 0;     // too large to store densely: PCG
+    if (p > 2304 || nb * p * p * 8 > ((int64_t)3 << 29)) return 0;     // too large to store densely: PCG
     d.g.n = L.nloc; d.g.p = (int)p; d.g.plane = (int)plane; d.g.nb = (int)nb; d.g.W = L.W;
     const size_t pw = (size_t)nb * p * L.W, np = (size_t)nb * p, pp = (size_t)p * p;
     double *A = nullptr, *B = nullptr, *P = nullptr;       // A: block being inverted, B: row panel, P: pivot block
@@ -1849,6 +1914,40 @@ int build_row_classes(mg_context* c, Level& L) {
 // Stencil classes of an offset-coded level that did not qualify for symmetric diagonals (wide stencils: P2): a
 // dictionary of its distinct rows -- the W (offset, value) pairs in stored order, bit for bit -- built and verified on
 // the device; levels with more than 255 distinct rows go without.
+// What the plane march of mg_lattice.hip.h needs on top of the stencil classes: every entry's offset as (di, dj, dk)
+// with |d| <= 2 (else the level keeps the gathering kernel), and the LM_K most frequent classes.
+int prepare_lat_march(mg_context* c, Level& L) {
+    L.lm_ntop = 0;
+    if (L.flat || L.g.ny < 5 || L.g.nx < 5 || !L.scls) return 0;
+    const size_t n = (size_t)256 * L.W;
+    std::vector<int> off(n), cnt(256), pack(n, 0), hist(256, 0);
+    HIP_TRY(hipMemcpy(off.data(), L.s_off, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cnt.data(), L.s_cnt, 256 * sizeof(int), hipMemcpyDeviceToHost));
+    const int64_t P = L.g.plane, nx = L.g.nx;
+    for (int cl = 0; cl < L.nscls; ++cl)
+        for (int t = 0; t < cnt[cl]; ++t) {
+            const int64_t o = off[(size_t)cl * L.W + t];
+            const int64_t dk = (o + (o >= 0 ? P / 2 : -(P / 2))) / P, rem = o - dk * P;
+            const int64_t dj = (rem + (rem >= 0 ? nx / 2 : -(nx / 2))) / nx, di = rem - dj * nx;
+            if (std::llabs(dk) > 2 || std::llabs(dj) > 2 || std::llabs(di) > 2) return 0;
+            pack[(size_t)cl * L.W + t] = (int)(((dk + 2) << 16) | ((dj + 2) * LM_PX + (di + 2)));
+        }
+    int* d_hist = reinterpret_cast<int*>(c->partials);
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(lm_class_histogram, dim3(1024), dim3(256), 0, c->stream, L.scls, L.nloc, d_hist);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int> order(L.nscls);
+    for (int i = 0; i < L.nscls; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hist[x] > hist[y]; });
+    MG_TRY(dev_alloc(c, &L.s_pack, n));
+    HIP_TRY(hipMemcpy(L.s_pack, pack.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    L.lm_ntop = std::min<int>(LM_K, L.nscls);
+    for (int t = 0; t < L.lm_ntop; ++t) L.lm_top[t] = order[t];
+    return 0;
+}
+
 int build_stencil_classes(mg_context* c, Level& L) {
     if (!c->use_classes || !L.coded || L.sdia || L.flat || L.W < 8) return 0;
     struct Scratch {
@@ -1899,7 +1998,7 @@ int build_stencil_classes(mg_context* c, Level& L) {
         return rc;
     }
     L.scls = cls; L.s_off = s_off; L.s_val = s_val; L.s_cnt = s_cnt; L.nscls = h[0];
-    return 0;
+    return prepare_lat_march(c, L);
 }
 
 // Symmetric diagonal storage: possible when the level is offset-coded, its offsets come in +/- pairs
@@ -2323,6 +2422,13 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_2d_k") {
         if (value < 2 || value > 5) return fail("fuse_2d_k must be in 2..5");
         c->fuse_2d_k = (int)value;
+    } else if (k == "lattice_march") {
+        c->lattice_march = value != 0;
+    } else if (k == "lattice_march_min_rows") {
+        c->lattice_march_min_rows = value;
+    } else if (k == "lattice_segments") {
+        if (value < 0 || value > 4096) return fail("lattice_segments must be in 0..4096");
+        c->lattice_segments = (int)value;
     } else if (k == "fuse_xcd_chunk") {
         if (value < 1 || value > 512) return fail("fuse_xcd_chunk must be in 1..512");
         c->fuse_xcd_chunk = (int)value;

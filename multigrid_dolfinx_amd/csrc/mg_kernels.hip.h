@@ -1429,18 +1429,29 @@ struct ProlongTable {
 template <bool ADD, bool KEEP>
 __global__ void prolong_table(Grid gc, Grid gf, ProlongTable t, const double* __restrict__ vc, double* __restrict__ vf,
                               double* __restrict__ err) {
+    // the table in LDS, offsets already as element distances on the coarse grid (lanes of a wave differ in residue:
+    // from global memory every entry cost four more loads per lane)
+    __shared__ int s_cnt[64];
+    __shared__ int64_t s_lin[640];
+    __shared__ double s_w[640];
+    for (int e = threadIdx.x; e < 640; e += blockDim.x) {
+        const int* o = t.off + (size_t)e * 3;
+        s_lin[e] = (int64_t)o[2] * gc.plane + (int64_t)o[1] * gc.nx + o[0];
+        s_w[e] = t.w[e];
+        if (e < 64) s_cnt[e] = t.count[e];
+    }
+    __syncthreads();
     int i, j;
     if (!plane_node(gf, &i, &j)) return;
     const int kl = blockIdx.y;
     const int k = gf.k0 + kl;
     const int res = (i & 3) | (gf.refine_y ? (j & 3) << 2 : 0) | (k & 3) << 4;
     const int bi = 2 * (i >> 2), bj = gf.refine_y ? 2 * (j >> 2) : j, bk = 2 * (k >> 2);
-    const int n = t.count[res];
+    const int n = s_cnt[res];
+    const double* const base = vc + gc.lead + (int64_t)(bk - gc.k0) * gc.plane + (int64_t)bj * gc.nx + bi;
     double s = 0.0;
     for (int e = 0; e < n; ++e) {
-        const int* o = t.off + ((size_t)res * 10 + e) * 3;
-        const int64_t src = gc.lead + (int64_t)(bk + o[2] - gc.k0) * gc.plane + (int64_t)(bj + o[1]) * gc.nx + (bi + o[0]);
-        const double term = t.w[(size_t)res * 10 + e] * vc[src];
+        const double term = s_w[res * 10 + e] * base[s_lin[res * 10 + e]];
         s = e == 0 ? term : s + term;
     }
     const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + i;
@@ -1460,6 +1471,22 @@ struct RestrictTable {
 };
 
 __global__ void restrict_table(Grid gc, Grid gf, RestrictTable t, const double* __restrict__ rf, double* __restrict__ fc) {
+    // the table in LDS (up to RT_MAX entries per type; longer tables are read from global memory as before)
+    constexpr int RT_MAX = 64;
+    __shared__ int s_cnt[8];
+    __shared__ int s_off[8 * RT_MAX];          // (o0 + 8) | (o1 + 8) << 8 | (o2 + 8) << 16
+    __shared__ double s_w[8 * RT_MAX];
+    const bool lds = t.M <= RT_MAX;
+    if (lds) {
+        for (int e = threadIdx.x; e < 8 * t.M; e += blockDim.x) {
+            const int typ = e / t.M, k = e - typ * t.M;
+            const int* o = t.off + (size_t)e * 3;
+            s_off[typ * RT_MAX + k] = (o[0] + 8) | (o[1] + 8) << 8 | (o[2] + 8) << 16;
+            s_w[typ * RT_MAX + k] = t.w[e];
+        }
+        if (threadIdx.x < 8) s_cnt[threadIdx.x] = t.count[threadIdx.x];
+    }
+    __syncthreads();
     int i, j;
     if (!plane_node(gc, &i, &j)) return;
     const int kl = blockIdx.y;
@@ -1471,14 +1498,24 @@ __global__ void restrict_table(Grid gc, Grid gf, RestrictTable t, const double* 
         s = rf[gf.lead + (int64_t)(fk - gf.k0) * gf.plane + (int64_t)fj * gf.nx + fi];
     } else {
         const int typ = (i & 1) | (gf.refine_y ? (j & 1) << 1 : 0) | (K & 1) << 2;
-        const int n = t.count[typ];
+        const int n = lds ? s_cnt[typ] : t.count[typ];
         bool first = true;
         for (int e = 0; e < n; ++e) {
-            const int* o = t.off + ((size_t)typ * t.M + e) * 3;
-            const int ii = fi + o[0], jj = fj + o[1], kk = fk + o[2];
+            int o0, o1, o2;
+            double w;
+            if (lds) {
+                const int pk = s_off[typ * RT_MAX + e];
+                o0 = (pk & 255) - 8; o1 = (pk >> 8 & 255) - 8; o2 = (pk >> 16 & 255) - 8;
+                w = s_w[typ * RT_MAX + e];
+            } else {
+                const int* o = t.off + ((size_t)typ * t.M + e) * 3;
+                o0 = o[0]; o1 = o[1]; o2 = o[2];
+                w = t.w[(size_t)typ * t.M + e];
+            }
+            const int ii = fi + o0, jj = fj + o1, kk = fk + o2;
             if (ii <= 0 || ii >= gf.nx - 1 || kk <= 0 || kk >= gf.nz - 1) continue;
             if (gf.refine_y && (jj <= 0 || jj >= gf.ny - 1)) continue;
-            const double term = t.w[(size_t)typ * t.M + e] * rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii];
+            const double term = w * rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii];
             s = first ? term : s + term;
             first = false;
         }

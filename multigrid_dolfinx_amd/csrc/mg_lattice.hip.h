@@ -1,0 +1,285 @@
+// Plane march for wide lattice stencils (P2 levels of BASELINE config 5) read through stencil classes.
+//
+// ell_cls_apply (mg_kernels.hip.h) gathers every neighbour of a row from global memory: a P2 row has 23 entries on
+// average (51 at most), so each x value is fetched ~23 times through L1 / L2 and the kernel runs at the rate of those
+// gathers (4.5 ms per sweep of the 513^3 lattice, 9 % of what its 25 bytes per row need).  Here a workgroup marches a
+// 64 x 16 tile of the grid along z with the five planes k-2 .. k+2 of x (tile + two cells of rim) in LDS: x comes from
+// global memory once per tile (x 1.33 for the rim) and the 23 gathers per row are LDS reads.
+//
+// Lanes are dealt by lattice PARITY: the (i, j) parities of a wave's 64 cells are equal, the plane's k parity is equal
+// anyway, so away from the boundary all lanes of a wave have the same stencil class and the class's (offset, value) pairs
+// are wave-uniform: they are read from an LDS copy of the level's most frequent classes (the eight interior parity types)
+// as broadcast reads.  Waves whose lanes differ in class -- tiles on the boundary -- run the pairs per lane from the
+// global table like ell_cls_apply does.  Either way a row's entries are applied in stored order with the same fma chain
+// and the same epilogue as ell_cls_apply: results are bit-identical.
+//
+//   Jacobi / residual: every cell of the plane; wave w owns the parity (w & 1, w >> 1), four cells per lane.
+//   Gauss-Seidel colour (in place): only the planes and cells of that colour; all four waves share its cells, one per lane.
+//     A colour never reads its own colour, so the stale LDS copies of the cells a launch updates are never used.
+//
+// LDS: 6 x 68 x 20 doubles (65 KB: planes k-2 .. k+2 are read while k+3 is written, one barrier per plane) + the class
+// tables (8 classes x 52 entries x 32 B: 13 KB): two workgroups per CU.
+#pragma once
+
+namespace mgk {
+
+constexpr int LM_TI = 64, LM_TJ = 16;                       // tile (cells with results)
+constexpr int LM_PX = LM_TI + 4, LM_PY = LM_TJ + 4;         // + rim of two
+constexpr int LM_PS = LM_PX * LM_PY;                        // cells per LDS plane
+constexpr int LM_NS = 6;                                    // plane slots: k-2 .. k+2 are read while k+3 arrives
+constexpr int LM_K = 8;                                     // classes with an LDS copy
+constexpr int LM_THREADS = 256;
+constexpr int LM_LOADS = (LM_PS + LM_THREADS - 1) / LM_THREADS;
+constexpr int LM_NST = 2;                                   // register stages of the plane loads: plane k+3+LM_NST-1 is requested at step k
+constexpr int LM_CENTER = 2 * LM_PX + 2;                    // in-plane offset of the cell itself (rim of two)
+
+struct LatArgs {
+    const double* x;            // row-based source (GS: also the destination)
+    const double* f;            // row-based
+    double* out;                // row-based
+    const unsigned char* cls;   // row-based class of every owned row
+    const int* s_pack;          // 256 x W: (dk + 2) << 16 | (dj + 2) * LM_PX + (di + 2) of every entry
+    const double* s_val;        // 256 x W
+    const int* s_cnt;           // 256
+    int W, WP, ntop;            // WP = table pitch in LDS: W rounded up to a multiple of 4, + 4 (the loop reads one group ahead)
+    int top[LM_K];              // classes copied to LDS (most frequent first)
+    int64_t nloc, xlo, xhi, P;  // owned rows; rows [xlo, xhi) of x exist (halo planes of a slab); plane size
+    int nx, ny, nz;             // owned planes nz
+    int kg0;                    // global index of local plane 0 (colours)
+    int color;
+    double omega;
+    int ntx, nty, seglen;
+    unsigned nitems, xcd_chunk;
+};
+
+inline size_t lm_lds_bytes(int W) {
+    const size_t WP = (size_t)(W + 3) / 4 * 4 + 4;
+    return sizeof(double) * (LM_NS * (size_t)LM_PS + LM_K * WP + LM_K) + sizeof(int) * (LM_NS * LM_K * WP + LM_K + 256 / 4);
+}
+
+// device histogram of the class bytes (set-up: which classes get the LDS copy)
+__global__ void lm_class_histogram(const unsigned char* __restrict__ cls, int64_t n, int* __restrict__ hist) {
+    __shared__ int h[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&h[cls[i]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
+    constexpr int NC = MODE == MODE_GS ? 1 : 4;
+    extern __shared__ double lm_smem[];
+    const int WP = a.WP;
+    double* const xs = lm_smem;                                     // LM_NS planes, plane p in slot p mod LM_NS
+    double* const tval = xs + LM_NS * LM_PS;                        // [slot][t], padded with zeros to a multiple of 4
+    double* const tdval = tval + LM_K * WP;                         // [slot]: the diagonal entry (1 if none / zero)
+    int* const toff = reinterpret_cast<int*>(tdval + LM_K);         // [k mod LM_NS][slot][t]: LDS offset of the entry's cell
+    int* const tcnt = toff + LM_NS * LM_K * WP;                     // [slot]: entries, rounded up to a multiple of 4
+    unsigned char* const tslot = reinterpret_cast<unsigned char*>(tcnt + LM_K);     // [class] -> slot, 255 = no LDS copy
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3, ch = a.xcd_chunk;
+        id = ((j / ch) * 8u + xcd) * ch + (j % ch);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = (int)(id / ntile);
+    const unsigned t_ = id % ntile;
+    const int i0 = (int)(t_ % (unsigned)a.ntx) * LM_TI, j0 = (int)(t_ / (unsigned)a.ntx) * LM_TJ;
+    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    if (z1 <= z0) return;
+
+    // ---- class tables of the LDS-resident classes ----
+    constexpr int DIAG = (2 << 16) | LM_CENTER;
+    for (int e = tid; e < a.ntop * WP; e += LM_THREADS) {
+        const int s = e / WP, t = e - s * WP, c = a.top[s];
+        const bool real = t < a.s_cnt[c];
+        // (padding: 0 * x of the cell itself, which leaves the sum as it is)
+        tval[e] = real ? a.s_val[(size_t)c * a.W + t] : 0.0;
+        const int pk = real ? a.s_pack[(size_t)c * a.W + t] : DIAG;
+#pragma unroll
+        for (int m = 0; m < LM_NS; ++m) toff[(m * LM_K + s) * WP + t] = ((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + (pk & 0xffff);
+    }
+    tslot[tid] = 255;
+    __syncthreads();
+    if (tid < a.ntop) {
+        const int c = a.top[tid], n = a.s_cnt[c];
+        double d = 1.0;
+        for (int t = 0; t < n; ++t)
+            if (a.s_pack[(size_t)c * a.W + t] == DIAG && a.s_val[(size_t)c * a.W + t] != 0.0) d = a.s_val[(size_t)c * a.W + t];
+        tdval[tid] = d;
+        tcnt[tid] = (n + 3) & ~3;
+        tslot[c] = (unsigned char)tid;
+    }
+
+    // ---- this thread's cells ----
+    int pi, pj, pk_ = 0;
+    if (MODE == MODE_GS) {
+        const int par = a.color == 8 ? 0 : a.color;
+        pi = par & 1; pj = (par >> 1) & 1; pk_ = (par >> 2) & 1;
+    } else {
+        pi = pj = 0;            // per cell, below
+    }
+    int cbase[NC];              // LDS offset of the cell inside a plane (the entries' offsets carry the rim)
+    int64_t crow[NC];           // row of the cell in plane 0
+    bool cok[NC];
+    int chalf[NC];              // (i >> 1) + (j >> 1): splits the vertex type into the colours 0 and 8
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        // Jacobi / residual: cell c of wave w has the parity (w + c) & 3 -- every wave gets each parity once per plane, so
+        // the 51-entry vertex rows are spread over the waves
+        const int par2 = MODE == MODE_GS ? (pi | (pj << 1)) : ((wave + c) & 3);
+        const int ci = 2 * (lane & 31) + (par2 & 1);
+        const int cj = 2 * ((MODE == MODE_GS ? 2 * wave : 2 * c) + (lane >> 5)) + (par2 >> 1);
+        cbase[c] = cj * LM_PX + ci;
+        crow[c] = (int64_t)(j0 + cj) * a.nx + (i0 + ci);
+        cok[c] = i0 + ci < a.nx && j0 + cj < a.ny;
+        chalf[c] = ((i0 + ci) >> 1) + ((j0 + cj) >> 1);
+    }
+    // ---- this thread's share of a plane's loads (tile + rim) ----
+    // One scalar base per plane + a 32-bit element offset per load, fixed for the march; cells outside the grid read the
+    // nearest cell inside and planes outside the vector the nearest plane inside (whole planes exist or not: the halo of a
+    // slab), zeros are selected afterwards: no load sits under a branch.
+    unsigned goff[LM_LOADS];
+    bool gok[LM_LOADS];
+#pragma unroll
+    for (int q = 0; q < LM_LOADS; ++q) {
+        const int e = tid + q * LM_THREADS;
+        const int lj = e / LM_PX, li = e - lj * LM_PX;
+        const int gi = i0 - 2 + li, gj = j0 - 2 + lj;
+        gok[q] = e < LM_PS && gi >= 0 && gi < a.nx && gj >= 0 && gj < a.ny;
+        goff[q] = (unsigned)(min(max(gj, 0), a.ny - 1) * a.nx + min(max(gi, 0), a.nx - 1));
+    }
+    const int plo = (int)(a.xlo / a.P), phi = (int)(a.xhi / a.P);       // planes [plo, phi) of x exist
+    auto load_plane = [&](int p, double (&r)[LM_LOADS]) {
+        const bool pok = p >= plo && p < phi;
+        const double* const xb = a.x + (int64_t)min(max(p, plo), phi - 1) * a.P;
+#pragma unroll
+        for (int q = 0; q < LM_LOADS; ++q) {
+            const double v = xb[goff[q]];
+            r[q] = (gok[q] && pok) ? v : 0.0;
+        }
+    };
+    auto store_plane = [&](int p, const double (&r)[LM_LOADS]) {
+        double* const dst = xs + ((p + LM_NS) % LM_NS) * LM_PS;            // (p >= -2)
+#pragma unroll
+        for (int q = 0; q < LM_LOADS; ++q) {
+            const int e = tid + q * LM_THREADS;
+            if ((q + 1) * LM_THREADS <= LM_PS || e < LM_PS) dst[e] = r[q];
+        }
+    };
+    // is this thread's cell c a row this launch relaxes in plane k?
+    auto active = [&](int c, int k) -> bool {
+        bool act = cok[c] && crow[c] + (int64_t)k * a.P < a.nloc;
+        if (MODE == MODE_GS) {
+            const int kg = a.kg0 + k;
+            act = act && (kg & 1) == pk_;
+            if (a.color == 0 || a.color == 8) act = act && (((chalf[c] + (kg >> 1)) & 1) ? 8 : 0) == a.color;
+        }
+        return act;
+    };
+    // class and right-hand side of the cells, one plane ahead of their use
+    int cl_n[NC];
+    double f_n[NC];
+    auto load_cf = [&](int k) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            // (unconditional: a row outside the level reads the last row; such cells are never relaxed)
+            const int64_t row = min(crow[c] + (int64_t)min(k, a.nz - 1) * a.P, a.nloc - 1);
+            cl_n[c] = (int)a.cls[row];
+            f_n[c] = a.f[row];
+        }
+    };
+
+    // One plane of the march.  The plane loaded into `rs` LM_NST-1 steps ago (k+3) is stored at the end; the loads of plane
+    // k+3+LM_NST-1 into `rl` are issued first and have LM_NST-1 steps to arrive (the march is unrolled over the register
+    // stages, so nothing is copied behind a load).
+    auto step = [&](const int k, const double (&rs)[LM_LOADS], double (&rl)[LM_LOADS]) {
+        int cl[NC];
+        double fr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { cl[c] = cl_n[c]; fr[c] = f_n[c]; }
+        // (classes and f first: loads return in order, and the next plane wants these while `rl` may stay in flight)
+        load_cf(k + 1);
+        load_plane(k + 3 + LM_NST - 1, rl);
+        const int m = (k % LM_NS + LM_NS) % LM_NS;
+        if (MODE != MODE_GS || ((a.kg0 + k) & 1) == pk_) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!active(c, k)) continue;
+                const int64_t row = crow[c] + (int64_t)k * a.P;
+                const int c0 = __builtin_amdgcn_readfirstlane(cl[c]);
+                const int slot = tslot[c0];
+                const bool uniform = __ballot(cl[c] != c0) == 0ull && slot != 255;
+                const double* const xc = xs + cbase[c];
+                const double xr = xc[m * LM_PS + LM_CENTER];
+                double s_ = 0.0, diag;
+                if (uniform) {
+                    const int n = __builtin_amdgcn_readfirstlane(tcnt[slot]);
+                    const double* const pv = tval + slot * WP;
+                    const int* const po = toff + (m * LM_K + slot) * WP;
+                    diag = tdval[slot];
+                    // four entries per turn; the (value, offset) pairs of the next turn are read while this turn's x values
+                    // arrive (the tables have four entries of slack behind the last group)
+                    double v0 = pv[0], v1 = pv[1], v2 = pv[2], v3 = pv[3];
+                    int o0 = __builtin_amdgcn_readfirstlane(po[0]), o1 = __builtin_amdgcn_readfirstlane(po[1]);
+                    int o2 = __builtin_amdgcn_readfirstlane(po[2]), o3 = __builtin_amdgcn_readfirstlane(po[3]);
+                    for (int t = 0; t < n; t += 4) {
+                        const double x0 = xc[o0], x1 = xc[o1], x2 = xc[o2], x3 = xc[o3];
+                        const double w0 = pv[t + 4], w1 = pv[t + 5], w2 = pv[t + 6], w3 = pv[t + 7];
+                        const int q0 = po[t + 4], q1 = po[t + 5], q2 = po[t + 6], q3 = po[t + 7];
+                        s_ = fma(v0, x0, s_);
+                        s_ = fma(v1, x1, s_);
+                        s_ = fma(v2, x2, s_);
+                        s_ = fma(v3, x3, s_);
+                        v0 = w0; v1 = w1; v2 = w2; v3 = w3;
+                        o0 = __builtin_amdgcn_readfirstlane(q0); o1 = __builtin_amdgcn_readfirstlane(q1);
+                        o2 = __builtin_amdgcn_readfirstlane(q2); o3 = __builtin_amdgcn_readfirstlane(q3);
+                    }
+                } else {
+                    const int n = a.s_cnt[cl[c]];
+                    const int* const pp = a.s_pack + (size_t)cl[c] * a.W;
+                    const double* const pv = a.s_val + (size_t)cl[c] * a.W;
+                    diag = 1.0;
+                    for (int t = 0; t < n; ++t) {
+                        const int pk = pp[t];
+                        const double v = pv[t];
+                        const double xv = xc[((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + (pk & 0xffff)];
+                        if (pk == DIAG && v != 0.0) diag = v;
+                        s_ = fma(v, xv, s_);
+                    }
+                }
+                a.out[row] = MODE == MODE_RESIDUAL ? fr[c] - s_ : xr + (a.omega * (1.0 / diag)) * (fr[c] - s_);
+            }
+        }
+        store_plane(k + 3, rs);                                     // slot (k-3) mod 6: last read a step ago
+        __syncthreads();
+    };
+
+    double rr[LM_NST][LM_LOADS];
+    for (int p = z0 - 2; p <= z0 + 2; ++p) {
+        load_plane(p, rr[0]);
+        store_plane(p, rr[0]);
+    }
+#pragma unroll
+    for (int st = 0; st < LM_NST - 1; ++st) load_plane(z0 + 3 + st, rr[st]);
+    load_cf(z0);
+    __syncthreads();
+    for (int k = z0; k < z1;) {
+#pragma unroll
+        for (int st = 0; st < LM_NST; ++st) {
+            if (k < z1) {
+                step(k, rr[st], rr[(st + LM_NST - 1) % LM_NST]);
+                ++k;
+            }
+        }
+    }
+}
+
+}  // namespace mgk

@@ -890,6 +890,44 @@ def test_p2_table_prolongation_matches_oracle(dim, cells, seed):
         assert np.all(np.abs(dev.vcycle(2, 4, residuals=True) - res_q1) <= 1e-12 * res_q1)
 
 
+@pytest.mark.parametrize("c,lo,hi", [(4, 1, 3), (8, 1, 3), (6, 1, 3)])
+def test_lattice_plane_march_equals_the_gathering_kernel(c, lo, hi):
+    """P2 levels as a plane march with x in LDS (`lat_march`, mg_lattice.hip.h) against the kernel it replaces
+    (`ell_cls_apply`, every neighbour gathered from global memory): residual, weighted-Jacobi sweeps, every colour of the
+    nine-colour Gauss-Seidel sweep and whole cycles, bit for bit -- both apply a row's entries in stored order.  Lattices
+    of 17^3 .. 49^3 points: tiles that stick out of the grid on every side, boundary classes in every wave, a level
+    size (6 * 8 + 1) that is no multiple of the tile."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    rng = np.random.default_rng(31)
+    with DeviceHierarchy.synthetic_p2(3, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, lattice_march=0) as ref, \
+            DeviceHierarchy.synthetic_p2(3, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, lattice_march=1,
+                                         lattice_march_min_rows=0, lattice_segments=2) as new:
+        n = ref.level_info(hi)["n_global"]
+        v = rng.standard_normal((n, 1))
+        f = rng.standard_normal((n, 1))
+        out = {}
+        for name, dev in (("ref", ref), ("new", new)):
+            got = []
+            dev.set_vector(hi, "f", f)
+            dev.set_vector(hi, "v", v)
+            dev.residual(hi)
+            got.append(dev.get_vector(hi, "r"))
+            dev.set_params(3, 3, 0.6, smoother="jacobi")
+            dev.smooth(hi, 3)
+            got.append(dev.get_vector(hi, "v"))
+            dev.set_params(2, 2, 1.0, smoother="mcgs")
+            dev.set_vector(hi, "v", v)
+            dev.smooth(hi, 2)
+            got.append(dev.get_vector(hi, "v"))
+            dev.zero_vector(hi, "v")
+            got.append(np.asarray(dev.vcycle(hi, 2, residuals=True)))
+            got.append(dev.get_vector(hi, "v"))
+            out[name] = got
+        for k, (a, b) in enumerate(zip(out["ref"], out["new"])):
+            assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+        assert new.time_kernel("gs", hi, 1) > 0.0
+
+
 def test_config5_full_size_properties():
     """BASELINE config 5 at its full size on one GPU (P2 on the 513^3-point lattice, 135 M unknowns, nine-colour
     Gauss-Seidel; no reference and no oracle at this size): properties that do not depend on the size -- the quadratic
