@@ -1308,17 +1308,34 @@ int smooth(mg_context* c, int level, int nw) {
                 MG_TRY(exchange_halo(c, L, L.v2, stream));
                 return 0;
             };
-            if (overlap && plan.nseg >= 3) {
-                // The two boundary segments first, alone on the GPU (launched beside the interior they are dispatched
-                // AFTER it -- the event hop delays them -- and then finish late: measured, profiles/r02_slab_rank_*),
-                // then the interior segments on the main stream while everything that waits for the neighbours runs
-                // on the (high-priority) communication stream; the pair ends when both have.
-                MG_TRY(launch_jacobi2(c, L, plan, 0, plan.nseg - 1, 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+            // slices whose once-relaxed values the finishing sweep of the first / last slices reads
+            const int64_t reach = L.g.plane + L.g.nx + 2;
+            const int64_t lo2 = std::min(L.nslices, (lo_end * S + reach + S - 1) / S);
+            const int64_t hi2 = std::max<int64_t>(0, (hi_begin * S - reach) / S);
+            if (overlap && hi2 > lo2) {
+                // Everything that waits for the neighbours -- the first sweep of the planes next to them, the exchange of
+                // its boundary planes, the second sweep of the first / last slices, the exchange of the result -- runs
+                // on the (high-priority) communication stream from the start of the pair and needs nothing from the
+                // pass itself: four small operations beside ONE launch of the pass over the whole slab, which stores the
+                // second sweep of all other rows.  (Measured on one slab of eight, tools/slab_rank_probe.py: a separate
+                // boundary launch of the pass in front costs 0.1 ms of the pair's 0.8; beside the interior launch it
+                // is dispatched after it and finishes late.)  The first sweep of those few planes is computed twice.
                 HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
-                MG_TRY(launch_jacobi2(c, L, plan, 1, 1, plan.nseg - 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+                const J2Plan whole = jacobi2_plan(c, L, false, 0);
+                MG_TRY(launch_jacobi2(c, L, whole, 0, 1, whole.nseg, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, nullptr));
                 std::swap(c->stream, c->comm_stream);
-                const int rc = boundary_chain(c->stream);
+                const int rc = [&]() -> int {
+                    if (lo && hi)
+                        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.sw.rows, nullptr, nullptr, nullptr, 0,
+                                          lo2 + L.nslices - hi2, 0, lo2, hi2 - lo2));
+                    else if (lo)
+                        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.sw.rows, nullptr, nullptr, nullptr, 0, lo2));
+                    else if (hi)
+                        MG_TRY(launch_ell(c, L, MODE_JACOBI, false, L.v.base, L.f.rows, L.sw.rows, nullptr, nullptr, nullptr, hi2,
+                                          L.nslices - hi2));
+                    return boundary_chain(c->stream);
+                }();
                 std::swap(c->stream, c->comm_stream);
                 MG_TRY(rc);
                 HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));

@@ -21,5 +21,12 @@ echo "== slab probe" >> "$LOG"
 export MG_RCCL_LIBRARY=$R/tests/fake_rccl/libfake_rccl.so
 timeout -k 10 300 python tools/slab_overhead_probe.py 8 7 50 > "$OUT/${TAG}_slab8.txt" 2>&1; tail -2 "$OUT/${TAG}_slab8.txt" >> "$LOG"
 timeout -k 10 200 python tools/slab_overhead_probe.py 2 7 50 > "$OUT/${TAG}_slab2.txt" 2>&1; tail -1 "$OUT/${TAG}_slab2.txt" >> "$LOG"
+echo "== one slab of eight alone (loopback stand-in)" >> "$LOG"
+export MG_RCCL_LIBRARY=$R/tests/fake_rccl/libfake_rccl_loopback.so
+for mu in 50 2; do
+  for t in graph_comm=0 graph_comm=1; do
+    timeout -k 10 300 python tools/slab_rank_probe.py 8 7 $mu $t >> "$OUT/${TAG}_slab_rank.txt" 2>&1; tail -1 "$OUT/${TAG}_slab_rank.txt" >> "$LOG"
+  done
+done
 echo "== done" >> "$LOG"
 cat "$LOG"
