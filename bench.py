@@ -46,7 +46,7 @@ def kernel_source_sha():
     import hashlib
     hsh = hashlib.sha256()
     base = os.path.join(ROOT, "multigrid_dolfinx_amd", "csrc")
-    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
+    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_lattice.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
         try:
             hsh.update(open(os.path.join(base, name), "rb").read())
         except OSError:
@@ -398,7 +398,10 @@ def main():
     # formats do not move these bytes)
     csr_model_bytes = sweeps_per_launch * (12 * z_loc + 36 * n_loc)
     if gs_ms:
-        kernel_id = ("ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
+        # 3-D levels with stencil classes run the colour launches as a plane march with x in LDS (mg_lattice.hip.h)
+        march = has_classes and dim == 3 and "lattice_march=0" not in args.tune
+        kernel_id = ("lat_march<MODE_GS> x 9 colours" if march else
+                     "ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif small:
         kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
     elif multi_k:

@@ -202,6 +202,9 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "lds_pad"            dynamic LDS bytes per block on large levels = occupancy cap (32768)
  *     "overlap"            halo exchange on the communication stream behind the interior sweep (1)
  *     "overlap_min_rows"   ... only on levels with at least this many owned rows (4194304)
+ *     "slab_pair_form"     overlapped pair sweeps on slabs: 0 = the exchange chain computes its own first sweep of the boundary
+ *                          planes and runs beside ONE launch of the pass over the whole slab; 1 = the boundary segments of the
+ *                          pass first, then its interior segments beside the chain (0); bit-identical, every rank alike
  *     "graph_comm"         1 = V-cycles on slabs are captured into hipGraphs too, RCCL exchanges included (the calls are
  *                          stream operations on both streams of the overlapped sweeps); every rank must set it alike.
  *                          Needs the RCCL transport (mg_comm_init_rccl).  (0: validated against the in-process stand-in of

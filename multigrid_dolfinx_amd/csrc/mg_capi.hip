@@ -233,6 +233,7 @@ struct mg_context {
     int lattice_march = 1;          // wide lattice stencils (P2 levels) as a plane march with x in LDS (mg_lattice.hip.h)
     int64_t lattice_march_min_rows = 1 << 18;
     int lattice_segments = 0;       // plane segments per tile of that march, 0 = chosen from the tile count
+    int slab_pair_form = 0;         // overlapped pair sweeps on slabs: 0 = chain beside one launch of the pass, 1 = boundary segments first
     int graph_comm = 0;             // ... on slabs too: the RCCL exchanges are captured with the kernels (opt-in)
     uint64_t epoch = 1;             // bumped by every call that changes what a V-cycle launches
     std::vector<CycleGraph> graphs;
@@ -1312,7 +1313,22 @@ int smooth(mg_context* c, int level, int nw) {
             const int64_t reach = L.g.plane + L.g.nx + 2;
             const int64_t lo2 = std::min(L.nslices, (lo_end * S + reach + S - 1) / S);
             const int64_t hi2 = std::max<int64_t>(0, (hi_begin * S - reach) / S);
-            if (overlap && hi2 > lo2) {
+            if (overlap && c->slab_pair_form == 1 && plan.nseg >= 3) {
+                // ("slab_pair_form" 1.)  The two boundary segments of the pass first, alone on the GPU -- launched beside
+                // the interior they are dispatched AFTER it, the event hop delays them, and finish late --, then the
+                // interior segments on the main stream while the chain runs on the communication stream; the once-
+                // relaxed boundary planes come from the pass (`sw`).
+                MG_TRY(launch_jacobi2(c, L, plan, 0, plan.nseg - 1, 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+                HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+                MG_TRY(launch_jacobi2(c, L, plan, 1, 1, plan.nseg - 2, L.v.rows, L.f.rows, L.v2.rows, st_lo, st_hi, L.sw.rows));
+                std::swap(c->stream, c->comm_stream);
+                const int rc = boundary_chain(c->stream);
+                std::swap(c->stream, c->comm_stream);
+                MG_TRY(rc);
+                HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+            } else if (overlap && c->slab_pair_form != 1 && hi2 > lo2) {
                 // Everything that waits for the neighbours -- the first sweep of the planes next to them, the exchange of
                 // its boundary planes, the second sweep of the first / last slices, the exchange of the result -- runs
                 // on the (high-priority) communication stream from the start of the pair and needs nothing from the
@@ -2364,6 +2380,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "graph") {
         c->use_graph = value != 0;
+        return 0;
+    }
+    if (k == "slab_pair_form") {
+        if (value != 0 && value != 1) return fail("slab_pair_form must be 0 or 1");
+        c->slab_pair_form = (int)value;
         return 0;
     }
     if (k == "graph_comm") {

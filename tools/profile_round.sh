@@ -25,10 +25,16 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_$N.d" -- python3 "$R/bench.py" $SHORT > /dev/null 2> "$OUT/${TAG}_c4_pmc_$N.err"
   python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_$N.d" "$OUT/${TAG}_c4_pmc_$N.csv"
 done
+for C in FETCH_SIZE WRITE_SIZE; do
+  N=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
+  echo "pmc c5 $N"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_c5_pmc_$N.d" -- python3 "$R/bench.py" --config c5 $SHORT > /dev/null 2> "$OUT/${TAG}_c5_pmc_$N.err"
+  python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c5_pmc_$N.d" "$OUT/${TAG}_c5_pmc_$N.csv"
+done
 echo "sq"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq.d" -- python3 "$R/tools/pmc_jacobi2.py" > "$OUT/${TAG}_c4_pmc_sq.log" 2>&1
 python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq.d" "$OUT/${TAG}_c4_pmc_sq.csv"
 cd "$R"
 echo "plain"; python3 bench.py > "$OUT/${TAG}_c4_bench_untraced.json" 2> "$OUT/${TAG}_c4_untraced.err"
-rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d
+rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d "$OUT"/${TAG}_c5_pmc_*.d
 echo "done"
