@@ -232,6 +232,7 @@ struct mg_context {
     int comm_priority = 1;          // communication stream created with the highest priority (MG_COMM_PRIORITY=0: lowest)
     int lattice_march = 1;          // wide lattice stencils (P2 levels) as a plane march with x in LDS (mg_lattice.hip.h)
     int64_t lattice_march_min_rows = 1 << 18;
+    int lattice_tile = 0;           // tile of that march: 0 / 1 = 64 x 16 cells (256 threads), 2 = 128 x 16 (512 threads)
     int lattice_segments = 0;       // plane segments per tile of that march, 0 = chosen from the tile count
     int slab_pair_form = 0;         // overlapped pair sweeps on slabs: 0 = chain beside one launch of the pass, 1 = boundary segments first
     int graph_comm = 0;             // ... on slabs too: the RCCL exchanges are captured with the kernels (opt-in)
@@ -607,8 +608,36 @@ int allow_large_lds(mg_context* c, const void* kernel, size_t bytes);
 // Plane march of wide lattice stencils (mg_lattice.hip.h): 3-D grid levels with stencil classes whose entries reach at
 // most two cells / lines / planes (prepare_lat_march found them decomposable).
 bool lat_march_ok(const mg_context* c, const Level& L) {
-    return c->lattice_march && L.scls && L.s_pack && L.lm_ntop > 0 && !L.flat && L.g.ny >= LM_TJ && L.g.nx >= LM_TI / 2 &&
+    return c->lattice_march && L.scls && L.s_pack && L.lm_ntop > 0 && !L.flat && L.g.ny >= 16 && L.g.nx >= 32 &&
            L.nloc >= c->lattice_march_min_rows;
+}
+
+template <int TI, int TJ, int NT>
+int launch_lat_march_t(mg_context* c, const Level& L, LatArgs a, int mode) {
+    a.ntx = (L.g.nx + TI - 1) / TI; a.nty = (L.g.ny + TJ - 1) / TJ;
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    const size_t lds = lm_lds_bytes(L.W, TI, TJ);
+    const int per_cu = lds > (size_t)80 * 1024 ? 1 : 2;             // resident workgroups per CU
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    // about 6.5 rounds of the resident workgroups (measured on the 513^3 lattice: 5 .. 12 segments per tile within 4 %,
+    // the finer cuts ahead -- the rounds are not rigid), segments of at least 16 planes (5 planes of warm-up each)
+    int nseg = c->lattice_segments > 0 ? c->lattice_segments : (int)std::max<int64_t>(1, (13 * per_cu * cus / 2 + ntile - 1) / ntile);
+    nseg = std::max(1, std::min(nseg, std::max(1, L.g.nk / 16)));
+    a.seglen = (L.g.nk + nseg - 1) / nseg;
+    nseg = (L.g.nk + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    a.xcd_chunk = 16;
+    const int64_t group = 8 * (int64_t)a.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    void (*kern)(LatArgs) = mode == MODE_RESIDUAL ? lat_march<MODE_RESIDUAL, TI, TJ, NT>
+                          : mode == MODE_GS ? lat_march<MODE_GS, TI, TJ, NT> : lat_march<MODE_JACOBI, TI, TJ, NT>;
+    if (lds > (size_t)150 * 1024) return fail("lattice march: class tables too wide");
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)150 * 1024));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_lat_march(mg_context* c, const Level& L, int mode, const double* x_rows, const double* f_rows, double* out_rows,
@@ -621,29 +650,10 @@ int launch_lat_march(mg_context* c, const Level& L, int mode, const double* x_ro
     a.nloc = L.nloc; a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.P = L.g.plane;
     a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.kg0 = (int)(L.row0 / L.g.plane);
     a.color = color; a.omega = c->omega;
-    a.ntx = (L.g.nx + LM_TI - 1) / LM_TI; a.nty = (L.g.ny + LM_TJ - 1) / LM_TJ;
-    const int64_t ntile = (int64_t)a.ntx * a.nty;
-    // two workgroups per CU resident; a few rounds of them, each segment paying five planes of warm-up
-    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
-    // about 6.5 rounds of the 2 * cus resident workgroups (measured on the 513^3 lattice: 5 .. 12 segments per tile within
-    // 4 %, the finer cuts ahead -- the rounds are not rigid), segments of at least 16 planes (5 planes of warm-up each)
-    int nseg = c->lattice_segments > 0 ? c->lattice_segments : (int)std::max<int64_t>(1, (13 * cus + ntile - 1) / ntile);
-    nseg = std::max(1, std::min(nseg, std::max(1, L.g.nk / 16)));
-    a.seglen = (L.g.nk + nseg - 1) / nseg;
-    nseg = (L.g.nk + a.seglen - 1) / a.seglen;
-    const int64_t items = ntile * nseg;
-    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
-    a.nitems = (unsigned)items;
-    a.xcd_chunk = 16;
-    const int64_t group = 8 * (int64_t)a.xcd_chunk;
-    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
-    const size_t lds = lm_lds_bytes(L.W);
-    void (*kern)(LatArgs) = mode == MODE_RESIDUAL ? lat_march<MODE_RESIDUAL> : mode == MODE_GS ? lat_march<MODE_GS> : lat_march<MODE_JACOBI>;
-    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)80 * 1024));
-    if (lds > (size_t)80 * 1024) return fail("lattice march: class tables too wide");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(LM_THREADS), lds, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    // ("lattice_tile" 2: the wide tile moves 23 % fewer bytes but its one 512-thread workgroup per CU is slower than two of
+    //  256 -- 8.0 against 6.9 ms per Gauss-Seidel sweep of the 513^3 lattice: kept for experiments)
+    if (c->lattice_tile == 2 && L.g.nx >= 128) return launch_lat_march_t<128, 16, 512>(c, L, a, mode);
+    return launch_lat_march_t<64, 16, 256>(c, L, a, mode);
 }
 
 // out = op(A, x) over all owned slices of the level
@@ -1963,7 +1973,7 @@ int prepare_lat_march(mg_context* c, Level& L) {
             const int64_t dk = (o + (o >= 0 ? P / 2 : -(P / 2))) / P, rem = o - dk * P;
             const int64_t dj = (rem + (rem >= 0 ? nx / 2 : -(nx / 2))) / nx, di = rem - dj * nx;
             if (std::llabs(dk) > 2 || std::llabs(dj) > 2 || std::llabs(di) > 2) return 0;
-            pack[(size_t)cl * L.W + t] = (int)(((dk + 2) << 16) | ((dj + 2) * LM_PX + (di + 2)));
+            pack[(size_t)cl * L.W + t] = (int)(((dk + 2) << 16) | ((dj + 2) << 8) | (di + 2));
         }
     int* d_hist = reinterpret_cast<int*>(c->partials);
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), c->stream));
@@ -2464,6 +2474,9 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->lattice_march = value != 0;
     } else if (k == "lattice_march_min_rows") {
         c->lattice_march_min_rows = value;
+    } else if (k == "lattice_tile") {
+        if (value < 0 || value > 2) return fail("lattice_tile must be 0, 1 or 2");
+        c->lattice_tile = (int)value;
     } else if (k == "lattice_segments") {
         if (value < 0 || value > 4096) return fail("lattice_segments must be in 0..4096");
         c->lattice_segments = (int)value;

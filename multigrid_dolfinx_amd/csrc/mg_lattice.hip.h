@@ -13,32 +13,32 @@
 // global table like ell_cls_apply does.  Either way a row's entries are applied in stored order with the same fma chain
 // and the same epilogue as ell_cls_apply: results are bit-identical.
 //
-//   Jacobi / residual: every cell of the plane; wave w owns the parity (w & 1, w >> 1), four cells per lane.
+//   Jacobi / residual: every cell of the plane, four per lane; a wave's four cells have the four (i, j) parities, so the 51-entry
+//     vertex rows (the other types have 19 or 21 entries) are spread evenly over the waves.
 //   Gauss-Seidel colour (in place): only the planes and cells of that colour; all four waves share its cells, one per lane.
 //     A colour never reads its own colour, so the stale LDS copies of the cells a launch updates are never used.
 //
-// LDS: 6 x 68 x 20 doubles (65 KB: planes k-2 .. k+2 are read while k+3 is written, one barrier per plane) + the class
-// tables (8 classes x 52 entries x 32 B: 13 KB): two workgroups per CU.
+// LDS (64 x 16 tile): 6 x 68 x 20 doubles (65 KB: planes k-2 .. k+2 are read while k+3 is written, one barrier per plane) +
+// the class tables (8 classes x 56 entries x 32 B: 14 KB): two workgroups per CU.
 #pragma once
 
 namespace mgk {
 
-constexpr int LM_TI = 64, LM_TJ = 16;                       // tile (cells with results)
-constexpr int LM_PX = LM_TI + 4, LM_PY = LM_TJ + 4;         // + rim of two
-constexpr int LM_PS = LM_PX * LM_PY;                        // cells per LDS plane
+// Tile shapes: cells with results TI x TJ (+ a rim of two), NT threads.  64 x 16 x 256, two workgroups per CU, is what runs.
+// 128 x 16 x 512 (one per CU) moves fewer bytes -- a tile row of 132 cells is 9.25 cache lines for 8.25 lines of data where
+// one of 68 cells is 5.25 for 4.25, and the rim is 29 % instead of 33 %; measured at the L2 / fabric boundary the narrow
+// tile reads 2.77 GB per colour launch of the 513^3 lattice, 2.6 x the vector -- but is slower (8.0 against 6.9 ms per
+// Gauss-Seidel sweep): "lattice_tile" 2, kept for experiments.
 constexpr int LM_NS = 6;                                    // plane slots: k-2 .. k+2 are read while k+3 arrives
 constexpr int LM_K = 8;                                     // classes with an LDS copy
-constexpr int LM_THREADS = 256;
-constexpr int LM_LOADS = (LM_PS + LM_THREADS - 1) / LM_THREADS;
 constexpr int LM_NST = 2;                                   // register stages of the plane loads: plane k+3+LM_NST-1 is requested at step k
-constexpr int LM_CENTER = 2 * LM_PX + 2;                    // in-plane offset of the cell itself (rim of two)
 
 struct LatArgs {
     const double* x;            // row-based source (GS: also the destination)
     const double* f;            // row-based
     double* out;                // row-based
     const unsigned char* cls;   // row-based class of every owned row
-    const int* s_pack;          // 256 x W: (dk + 2) << 16 | (dj + 2) * LM_PX + (di + 2) of every entry
+    const int* s_pack;          // 256 x W: (dk + 2) << 16 | (dj + 2) << 8 | (di + 2) of every entry
     const double* s_val;        // 256 x W
     const int* s_cnt;           // 256
     int W, WP, ntop;            // WP = table pitch in LDS: W rounded up to a multiple of 4, + 4 (the loop reads one group ahead)
@@ -52,9 +52,9 @@ struct LatArgs {
     unsigned nitems, xcd_chunk;
 };
 
-inline size_t lm_lds_bytes(int W) {
-    const size_t WP = (size_t)(W + 3) / 4 * 4 + 4;
-    return sizeof(double) * (LM_NS * (size_t)LM_PS + LM_K * WP + LM_K) + sizeof(int) * (LM_NS * LM_K * WP + LM_K + 256 / 4);
+inline size_t lm_lds_bytes(int W, int TI, int TJ) {
+    const size_t WP = (size_t)(W + 3) / 4 * 4 + 4, PS = (size_t)(TI + 4) * (TJ + 4);
+    return sizeof(double) * (LM_NS * PS + LM_K * WP + LM_K) + sizeof(int) * (LM_NS * LM_K * WP + LM_K + 256 / 4);
 }
 
 // device histogram of the class bytes (set-up: which classes get the LDS copy)
@@ -68,9 +68,15 @@ __global__ void lm_class_histogram(const unsigned char* __restrict__ cls, int64_
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-template <int MODE>
+template <int MODE, int LM_TI, int LM_TJ, int LM_THREADS>
 __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
-    constexpr int NC = MODE == MODE_GS ? 1 : 4;
+    constexpr int LM_PX = LM_TI + 4, LM_PY = LM_TJ + 4, LM_PS = LM_PX * LM_PY;      // tile + rim; cells per LDS plane
+    constexpr int LM_LOADS = (LM_PS + LM_THREADS - 1) / LM_THREADS;
+    constexpr int LM_CENTER = 2 * LM_PX + 2;                    // in-plane offset of the cell itself (rim of two)
+    constexpr int NW = LM_THREADS / 64, HX = LM_TI / 2;
+    constexpr int NCP = (LM_TI / 2) * (LM_TJ / 2) / 64;        // wave-sized groups of cells per (i, j) parity
+    constexpr int NC = MODE == MODE_GS ? 1 : 4 * NCP / NW;
+    static_assert(NW % 4 == 0 && NCP == (NW / 4) * (4 * NCP / NW) && NCP <= NW, "tile shape / thread count");
     extern __shared__ double lm_smem[];
     const int WP = a.WP;
     double* const xs = lm_smem;                                     // LM_NS planes, plane p in slot p mod LM_NS
@@ -96,7 +102,8 @@ __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
     if (z1 <= z0) return;
 
     // ---- class tables of the LDS-resident classes ----
-    constexpr int DIAG = (2 << 16) | LM_CENTER;
+    constexpr int DIAG = (2 << 16) | (2 << 8) | 2;
+    auto inplane = [](int pk) -> int { return ((pk >> 8) & 255) * LM_PX + (pk & 255); };
     for (int e = tid; e < a.ntop * WP; e += LM_THREADS) {
         const int s = e / WP, t = e - s * WP, c = a.top[s];
         const bool real = t < a.s_cnt[c];
@@ -104,9 +111,9 @@ __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
         tval[e] = real ? a.s_val[(size_t)c * a.W + t] : 0.0;
         const int pk = real ? a.s_pack[(size_t)c * a.W + t] : DIAG;
 #pragma unroll
-        for (int m = 0; m < LM_NS; ++m) toff[(m * LM_K + s) * WP + t] = ((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + (pk & 0xffff);
+        for (int m = 0; m < LM_NS; ++m) toff[(m * LM_K + s) * WP + t] = ((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + inplane(pk);
     }
-    tslot[tid] = 255;
+    if (tid < 256) tslot[tid] = 255;
     __syncthreads();
     if (tid < a.ntop) {
         const int c = a.top[tid], n = a.s_cnt[c];
@@ -132,14 +139,18 @@ __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
     int chalf[NC];              // (i >> 1) + (j >> 1): splits the vertex type into the colours 0 and 8
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        // Jacobi / residual: cell c of wave w has the parity (w + c) & 3 -- every wave gets each parity once per plane, so
-        // the 51-entry vertex rows are spread over the waves
+        // The cells of one (i, j) parity form NCP groups of 64 (lane -> half-column, group -> half-rows).  Jacobi / residual:
+        // cell c of wave w has the parity (w + c) & 3 -- every wave gets each parity equally often per plane, so the
+        // 51-entry vertex rows are spread over the waves -- and the group (w >> 2) * NC + c.  A colour launch: wave w has
+        // group w of the colour's parity.
         const int par2 = MODE == MODE_GS ? (pi | (pj << 1)) : ((wave + c) & 3);
-        const int ci = 2 * (lane & 31) + (par2 & 1);
-        const int cj = 2 * ((MODE == MODE_GS ? 2 * wave : 2 * c) + (lane >> 5)) + (par2 >> 1);
+        const int grp = MODE == MODE_GS ? wave : (wave >> 2) * NC + c;
+        const int q = grp * 64 + lane;
+        const int ci = 2 * (q % HX) + (par2 & 1);
+        const int cj = 2 * (q / HX) + (par2 >> 1);
         cbase[c] = cj * LM_PX + ci;
         crow[c] = (int64_t)(j0 + cj) * a.nx + (i0 + ci);
-        cok[c] = i0 + ci < a.nx && j0 + cj < a.ny;
+        cok[c] = i0 + ci < a.nx && j0 + cj < a.ny && (MODE != MODE_GS || wave < NCP);
         chalf[c] = ((i0 + ci) >> 1) + ((j0 + cj) >> 1);
     }
     // ---- this thread's share of a plane's loads (tile + rim) ----
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
                     for (int t = 0; t < n; ++t) {
                         const int pk = pp[t];
                         const double v = pv[t];
-                        const double xv = xc[((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + (pk & 0xffff)];
+                        const double xv = xc[((m + (pk >> 16) + LM_NS - 2) % LM_NS) * LM_PS + inplane(pk)];
                         if (pk == DIAG && v != 0.0) diag = v;
                         s_ = fma(v, xv, s_);
                     }
