@@ -115,6 +115,7 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
     _capi.check(_capi.load().mg_comm_unique_id(buf, 128))
     uid = buf.raw
     results, errors = [None] * world, []
+    tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("MG_TEST_TUNE", "").split(",") if kv}
 
     def run(h):
         out = []
@@ -132,7 +133,7 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
                 h.set_tuning("overlap", overlap)
                 h.set_tuning("overlap_min_rows", 0)
                 h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
-            h = DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, halo_planes=2)
+            h = DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, halo_planes=2, **tune)
             info = h.level_info(hi)
             assert not info["replicated"] and info["n_local"] < info["n_global"]
             results[rank] = run(h)
@@ -149,7 +150,7 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
         t.join(timeout=240)
     assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
     assert not errors, errors
-    with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu) as ser:
+    with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, **tune) as ser:
         want = run(ser)
     for rank in range(world):
         got = results[rank]
