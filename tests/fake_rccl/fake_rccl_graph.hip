@@ -6,7 +6,7 @@
 //     receiver: k_wait_ready (spin) -> k_copy (many blocks) -> k_done (consumed = ++received)
 // so a whole slab V-cycle -- kernels and exchanges on two streams -- can be captured and replayed, which is what the
 // library's "graph_comm" path does with the real RCCL.  "Ranks" are threads of one process sharing one GPU.  Spins are
-// bounded (a few seconds, then an error word is set and the kernel gives up: wrong data, never a hang).  Collectives
+// bounded (15 s, then an error word is set and the kernel gives up: wrong data, never a hang).  Collectives
 // that the V-cycle itself never issues (all-reduce of norms) synchronise on the host.  Nothing here is shipped.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -31,7 +31,7 @@ struct Channel {
     unsigned long long pad;
 };
 
-constexpr long long kSpinLimit = 400000000ll;       // wall_clock64 ticks at 100 MHz: 4 s
+constexpr long long kSpinLimit = 1500000000ll;      // wall_clock64 ticks at 100 MHz: 15 s
 
 __global__ void k_post(Channel* ch, const void* ptr, unsigned long long bytes) {
     ch->ptr = ptr;
