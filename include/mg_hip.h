@@ -243,7 +243,7 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "pcg_chunk"          PCG iterations enqueued between convergence checks (16)
  *     "lattice_march"      wide lattice stencils (3-D P2 levels with stencil classes) as a plane march with five planes of x in
  *                          LDS instead of gathers from global memory (1); bit-identical either way
- *     "lattice_march_min_rows"  ... only on levels with at least this many owned rows (262144)
+ *     "lattice_march_min_rows"  ... only on levels with at least this many owned rows (4194304)
  *     "lattice_tile"       tile of that march: 0 / 1 = 64 x 16 cells (256 threads, two workgroups per CU), 2 = 128 x 16 where the
  *                          grid is 128 wide (512 threads, one per CU: fewer rim cells and partly used cache lines, but
  *                          measured slower) (0)

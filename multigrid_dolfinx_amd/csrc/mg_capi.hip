@@ -231,7 +231,7 @@ struct mg_context {
     int use_graph = 1;              // replay whole V-cycles as hipGraphs (single GPU, direct coarsest solve)
     int comm_priority = 1;          // communication stream created with the highest priority (MG_COMM_PRIORITY=0: lowest)
     int lattice_march = 1;          // wide lattice stencils (P2 levels) as a plane march with x in LDS (mg_lattice.hip.h)
-    int64_t lattice_march_min_rows = 1 << 18;
+    int64_t lattice_march_min_rows = 1 << 22;       // (measured on C5: the 129^3 and 65^3 lattices are faster with the gathering kernel)
     int lattice_tile = 0;           // tile of that march: 0 / 1 = 64 x 16 cells (256 threads), 2 = 128 x 16 (512 threads)
     int lattice_segments = 0;       // plane segments per tile of that march, 0 = chosen from the tile count
     int slab_pair_form = 0;         // overlapped pair sweeps on slabs: 0 = chain beside one launch of the pass, 1 = boundary segments first
@@ -619,9 +619,20 @@ int launch_lat_march_t(mg_context* c, const Level& L, LatArgs a, int mode) {
     const size_t lds = lm_lds_bytes(L.W, TI, TJ);
     const int per_cu = lds > (size_t)80 * 1024 ? 1 : 2;             // resident workgroups per CU
     const int64_t cus = std::max(1, c->prop.multiProcessorCount);
-    // about 6.5 rounds of the resident workgroups (measured on the 513^3 lattice: 5 .. 12 segments per tile within 4 %,
-    // the finer cuts ahead -- the rounds are not rigid), segments of at least 16 planes (5 planes of warm-up each)
-    int nseg = c->lattice_segments > 0 ? c->lattice_segments : (int)std::max<int64_t>(1, (13 * per_cu * cus / 2 + ntile - 1) / ntile);
+    // Segments per tile.  Many tiles (the 513^3 lattice: 297): about 6.5 rounds of the resident workgroups -- measured, 5 .. 12
+    // segments per tile are within 4 %, the finer cuts ahead: with that many workgroups the rounds are not rigid.  Few tiles
+    // (257^3: 85, 129^3: 27): the rounds are rigid, so the cut that minimises rounds x (planes per segment + 5 planes of
+    // warm-up); segments of at least 16 planes.
+    const int64_t resident = per_cu * cus;
+    int nseg = c->lattice_segments;
+    if (nseg <= 0 && 2 * ntile >= resident) nseg = (int)std::max<int64_t>(1, (13 * resident / 2 + ntile - 1) / ntile);
+    if (nseg <= 0) {
+        double best = 1e300;
+        for (int n = 1; n <= std::max(1, L.g.nk / 16); ++n) {
+            const double cost = (double)((ntile * n + resident - 1) / resident) * ((L.g.nk + n - 1) / n + 5.0);
+            if (cost < best) { best = cost; nseg = n; }
+        }
+    }
     nseg = std::max(1, std::min(nseg, std::max(1, L.g.nk / 16)));
     a.seglen = (L.g.nk + nseg - 1) / nseg;
     nseg = (L.g.nk + a.seglen - 1) / a.seglen;
