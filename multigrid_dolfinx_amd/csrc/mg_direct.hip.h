@@ -204,6 +204,33 @@ __global__ __launch_bounds__(BLOCK) void bt_forward(BtGeom g, int k, const int* 
     if (lane == 0) y[(size_t)k * g.p + i] = acc;
 }
 
+// The forward step in two launches, for rows with MANY couplings into the previous block (P2: ~20): z = T_{k-1} y_{k-1} once
+// (bt_matvec, one wave per row, the same dot products bt_forward forms -- per coupling and row -- and therefore the same
+// bits), then y_k = b_k - L_k z (bt_forward_sparse, one thread per row, couplings in stored order like bt_forward).
+__global__ __launch_bounds__(BLOCK) void bt_matvec(int p, const double* __restrict__ T, const double* __restrict__ w, double* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= p) return;
+    const double* Ti = T + (size_t)i * p;
+    double d = 0.0;
+    for (int c = lane; c < p; c += WAVE) d = fma(Ti[c], w[c], d);
+    d = wave_sum(d);
+    if (lane == 0) z[i] = d;
+}
+
+__global__ void bt_forward_sparse(BtGeom g, int k, const int* __restrict__ lcol, const double* __restrict__ lval,
+                                  const double* __restrict__ z, const double* __restrict__ b, double* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.p) return;
+    const int64_t row = (int64_t)k * g.p + i;
+    double acc = row < g.n ? b[row] : 0.0;
+    for (int s = 0; s < g.W; ++s) {
+        const double l = lval[(size_t)i * g.W + s];
+        if (l != 0.0) acc -= l * z[lcol[(size_t)i * g.W + s]];
+    }
+    y[(size_t)k * g.p + i] = acc;
+}
+
 // Backward step: x_k = T_k (y_k - U_k x_{k+1}); one wave per row of block k.  The corrected right-hand
 // side w = y_k - U_k x_{k+1} is formed first by `bt_backward_rhs` (rows with couplings only).
 __global__ void bt_backward_rhs(BtGeom g, int k, const int* __restrict__ ucol, const double* __restrict__ uval,
