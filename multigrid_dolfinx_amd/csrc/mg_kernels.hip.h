@@ -1472,7 +1472,7 @@ struct RestrictTable {
 
 __global__ void restrict_table(Grid gc, Grid gf, RestrictTable t, const double* __restrict__ rf, double* __restrict__ fc) {
     // the table in LDS (up to RT_MAX entries per type; longer tables are read from global memory as before)
-    constexpr int RT_MAX = 64;
+    constexpr int RT_MAX = 128;
     __shared__ int s_cnt[8];
     __shared__ int s_off[8 * RT_MAX];          // (o0 + 8) | (o1 + 8) << 8 | (o2 + 8) << 16
     __shared__ double s_w[8 * RT_MAX];
