@@ -400,7 +400,8 @@ def main():
     if gs_ms:
         # 3-D levels with stencil classes run the colour launches as a plane march with x in LDS (mg_lattice.hip.h)
         march = has_classes and dim == 3 and "lattice_march=0" not in args.tune
-        kernel_id = ("lat_march<MODE_GS> x 9 colours" if march else
+        pairs = march and args.gpus == 1 and "lattice_gs2=0" not in args.tune
+        kernel_id = ("lat_gs2 x 5 launches (two colours each)" if pairs else "lat_march<MODE_GS> x 9 colours" if march else
                      "ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif small:
         kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
@@ -477,7 +478,7 @@ def main():
                                       if args.gpus > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": kernel_id + (" (one fine-level Gauss-Seidel sweep = nine colour launches; kernel_ms is their sum"
+                         "kernel": kernel_id + (" (one fine-level nine-colour Gauss-Seidel sweep; kernel_ms is the sum of its launches"
                                                 if gs_ms else
                                                 f" ({sweeps_per_launch} fine-level weighted-Jacobi sweeps per launch" if pair_ms else
                                                 " (one fine-level weighted-Jacobi sweep per launch") +

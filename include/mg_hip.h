@@ -244,6 +244,9 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "lattice_march"      wide lattice stencils (3-D P2 levels with stencil classes) as a plane march with five planes of x in
  *                          LDS instead of gathers from global memory (1); bit-identical either way
  *     "lattice_march_min_rows"  ... only on levels with at least this many owned rows (4194304)
+ *     "lattice_gs2"        1 = the nine-colour Gauss-Seidel sweep on whole 3-D lattice levels runs two colours per launch, out of
+ *                          place (five passes over the vector instead of nine; the level's two iterate buffers swap);
+ *                          bit-identical, but measured slower (its nine plane slots only fit 32-wide tiles) (0)
  *     "lattice_tile"       tile of that march: 0 / 1 = 64 x 16 cells (256 threads, two workgroups per CU), 2 = 128 x 16 where the
  *                          grid is 128 wide (512 threads, one per CU: fewer rim cells and partly used cache lines, but
  *                          measured slower) (0)

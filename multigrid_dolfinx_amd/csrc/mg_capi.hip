@@ -232,6 +232,8 @@ struct mg_context {
     int comm_priority = 1;          // communication stream created with the highest priority (MG_COMM_PRIORITY=0: lowest)
     int lattice_march = 1;          // wide lattice stencils (P2 levels) as a plane march with x in LDS (mg_lattice.hip.h)
     int64_t lattice_march_min_rows = 1 << 22;       // (measured on C5: the 129^3 and 65^3 lattices are faster with the gathering kernel)
+    int lattice_gs2 = 0;            // nine-colour Gauss-Seidel on whole lattice levels: two colours per launch, out of place (lat_gs2;
+                                    // measured slower than nine colour launches: 9.1 against 6.8 ms per sweep of the 513^3 lattice)
     int lattice_tile = 0;           // tile of that march: 0 / 1 = 64 x 16 cells (256 threads), 2 = 128 x 16 (512 threads)
     int lattice_segments = 0;       // plane segments per tile of that march, 0 = chosen from the tile count
     int slab_pair_form = 0;         // overlapped pair sweeps on slabs: 0 = chain beside one launch of the pass, 1 = boundary segments first
@@ -910,6 +912,46 @@ bool fused_sweeps_ok(const mg_context* c, const Level& L, bool ignore_size = fal
 
 // Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per function (and device: one
 // device per handle); remembered in the handle.
+// One launch of the two-colour Gauss-Seidel pass (mg_lattice.hip.h, lat_gs2): colours c1 and c2 (c2 < 0: c1 only) of the
+// sweep that takes the level's iterate from `xold` to `xnew`.
+int launch_lat_gs2(mg_context* c, const Level& L, int c1, int c2, const double* xold_rows, double* xnew_rows) {
+    Gs2Args a{};
+    a.xold = xold_rows; a.xnew = xnew_rows; a.f = L.f.rows;
+    a.cls = L.scls; a.s_pack = L.s_pack; a.s_val = L.s_val; a.s_cnt = L.s_cnt;
+    a.W = L.W; a.WP = (L.W + 3) / 4 * 4 + 4; a.ntop = L.lm_ntop;
+    for (int t = 0; t < LM_K; ++t) a.top[t] = L.lm_top[t];
+    a.nloc = L.nloc; a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk;
+    a.c1 = c1; a.c2 = c2; a.omega = c->omega;
+    a.ntx = (L.g.nx + G2_TI - 1) / G2_TI; a.nty = (L.g.ny + G2_TJ - 1) / G2_TJ;
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    const int64_t resident = 2 * (int64_t)std::max(1, c->prop.multiProcessorCount);
+    // (as launch_lat_march_t; a segment pays 5 + 4 planes of warm-up and 3 of trailing second colour)
+    int nseg = c->lattice_segments;
+    if (nseg <= 0 && 2 * ntile >= resident) nseg = (int)std::max<int64_t>(1, (13 * resident / 2 + ntile - 1) / ntile);
+    if (nseg <= 0) {
+        double best = 1e300;
+        for (int n = 1; n <= std::max(1, L.g.nk / 16); ++n) {
+            const double cost = (double)((ntile * n + resident - 1) / resident) * ((L.g.nk + n - 1) / n + 12.0);
+            if (cost < best) { best = cost; nseg = n; }
+        }
+    }
+    nseg = std::max(1, std::min(nseg, std::max(1, L.g.nk / 16)));
+    a.seglen = (L.g.nk + nseg - 1) / nseg;
+    nseg = (L.g.nk + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    a.xcd_chunk = 16;
+    const int64_t group = 8 * (int64_t)a.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    const size_t lds = g2_lds_bytes(L.W);
+    if (lds > (size_t)80 * 1024) return fail("lattice march: class tables too wide");
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(lat_gs2), (size_t)80 * 1024));
+    hipLaunchKernelGGL(lat_gs2, dim3(grid), dim3(G2_THREADS), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int allow_large_lds(mg_context* c, const void* kernel, size_t bytes) {
     if (std::find(c->large_lds_kernels.begin(), c->large_lds_kernels.end(), kernel) != c->large_lds_kernels.end()) return 0;
     HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1259,12 +1301,21 @@ int smooth(mg_context* c, int level, int nw) {
         if (!L.mc_ok)
             return fail("the nine lattice colours are not a valid colouring of level " + std::to_string(level) +
                         " (needs a pruned P1 / P2 grid matrix)");
-        for (int s = 0; s < nw; ++s)
+        // whole 3-D lattice levels: two colours per launch, out of place (v -> v2, then the two swap)
+        const bool pairs = c->lattice_gs2 && c->class_sweeps && lat_march_ok(c, L) && (L.replicated || !c->comm.active());
+        for (int s = 0; s < nw; ++s) {
+            if (pairs) {
+                for (int color = 0; color < 9; color += 2)
+                    MG_TRY(launch_lat_gs2(c, L, color, color + 1 < 9 ? color + 1 : -1, L.v.rows, L.v2.rows));
+                std::swap(L.v, L.v2);
+                continue;
+            }
             for (int color = 0; color < 9; ++color) {
                 if (c->dim == 2 && (color & 2)) continue;            // (nx, 1, nz) storage: j is always 0
                 MG_TRY(launch_ell(c, L, MODE_GS, false, L.v.base, L.f.rows, L.v.rows, nullptr, nullptr, nullptr, 0, -1, color));
                 MG_TRY(exchange_halo(c, L, L.v));
             }
+        }
         return 0;
     }
     const bool dist = !L.replicated && c->comm.active();
@@ -2495,6 +2546,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->lattice_march = value != 0;
     } else if (k == "lattice_march_min_rows") {
         c->lattice_march_min_rows = value;
+    } else if (k == "lattice_gs2") {
+        c->lattice_gs2 = value != 0;
     } else if (k == "lattice_tile") {
         if (value < 0 || value > 2) return fail("lattice_tile must be 0, 1 or 2");
         c->lattice_tile = (int)value;

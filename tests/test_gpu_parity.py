@@ -890,18 +890,21 @@ def test_p2_table_prolongation_matches_oracle(dim, cells, seed):
         assert np.all(np.abs(dev.vcycle(2, 4, residuals=True) - res_q1) <= 1e-12 * res_q1)
 
 
-@pytest.mark.parametrize("c,lo,hi,tile", [(4, 1, 3, 1), (8, 1, 3, 1), (6, 1, 3, 1), (4, 1, 3, 2), (8, 1, 3, 2), (6, 1, 3, 2), (8, 2, 4, 0)])
-def test_lattice_plane_march_equals_the_gathering_kernel(c, lo, hi, tile):
+@pytest.mark.parametrize("c,lo,hi,tile,gs2", [(4, 1, 3, 1, 0), (8, 1, 3, 1, 0), (6, 1, 3, 1, 0), (4, 1, 3, 2, 0), (8, 1, 3, 2, 0),
+                                              (6, 1, 3, 2, 0), (8, 2, 4, 0, 0), (4, 1, 3, 0, 1), (8, 1, 3, 0, 1), (6, 1, 3, 0, 1),
+                                              (8, 2, 4, 0, 1)])
+def test_lattice_plane_march_equals_the_gathering_kernel(c, lo, hi, tile, gs2):
     """P2 levels as a plane march with x in LDS (`lat_march`, mg_lattice.hip.h) against the kernel it replaces
     (`ell_cls_apply`, every neighbour gathered from global memory): residual, weighted-Jacobi sweeps, every colour of the
     nine-colour Gauss-Seidel sweep and whole cycles, bit for bit -- both apply a row's entries in stored order.  Lattices
     of 17^3 .. 129^3 points, both tile shapes (64 x 16 and 128 x 16 cells): tiles that stick out of the grid on every side,
-    boundary classes in every wave, a level size (6 * 8 + 1) that is no multiple of the tile."""
+    boundary classes in every wave, a level size (6 * 8 + 1) that is no multiple of the tile.  `gs2`: the Gauss-Seidel sweep
+    with two colours per launch, out of place (`lat_gs2`) -- five launches instead of nine, the same bits."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(31)
     with DeviceHierarchy.synthetic_p2(3, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, lattice_march=0) as ref, \
             DeviceHierarchy.synthetic_p2(3, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, lattice_march=1,
-                                         lattice_march_min_rows=0, lattice_segments=2, lattice_tile=tile) as new:
+                                         lattice_march_min_rows=0, lattice_segments=2, lattice_tile=tile, lattice_gs2=gs2) as new:
         n = ref.level_info(hi)["n_global"]
         v = rng.standard_normal((n, 1))
         f = rng.standard_normal((n, 1))
