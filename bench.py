@@ -400,7 +400,7 @@ def main():
     if gs_ms:
         # 3-D levels with stencil classes run the colour launches as a plane march with x in LDS (mg_lattice.hip.h)
         march = has_classes and dim == 3 and "lattice_march=0" not in args.tune
-        pairs = march and args.gpus == 1 and "lattice_gs2=0" not in args.tune
+        pairs = march and args.gpus == 1 and "lattice_gs2=1" in args.tune            # (opt-in: measured slower)
         kernel_id = ("lat_gs2 x 5 launches (two colours each)" if pairs else "lat_march<MODE_GS> x 9 colours" if march else
                      "ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif small:
