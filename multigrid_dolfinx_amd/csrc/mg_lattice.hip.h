@@ -168,21 +168,20 @@ __global__ __launch_bounds__(LM_THREADS) void lat_march(LatArgs a) {
         goff[q] = (unsigned)(min(max(gj, 0), a.ny - 1) * a.nx + min(max(gi, 0), a.nx - 1));
     }
     const int plo = (int)(a.xlo / a.P), phi = (int)(a.xhi / a.P);       // planes [plo, phi) of x exist
+    // (the zeros are selected when a plane is STORED, steps after its loads were issued: a select right behind a load is an
+    //  instruction that waits for it, and the compiler then drains the loads at the end of the step that issued them)
     auto load_plane = [&](int p, double (&r)[LM_LOADS]) {
-        const bool pok = p >= plo && p < phi;
         const double* const xb = a.x + (int64_t)min(max(p, plo), phi - 1) * a.P;
 #pragma unroll
-        for (int q = 0; q < LM_LOADS; ++q) {
-            const double v = xb[goff[q]];
-            r[q] = (gok[q] && pok) ? v : 0.0;
-        }
+        for (int q = 0; q < LM_LOADS; ++q) r[q] = xb[goff[q]];
     };
     auto store_plane = [&](int p, const double (&r)[LM_LOADS]) {
+        const bool pok = p >= plo && p < phi;
         double* const dst = xs + ((p + LM_NS) % LM_NS) * LM_PS;            // (p >= -2)
 #pragma unroll
         for (int q = 0; q < LM_LOADS; ++q) {
             const int e = tid + q * LM_THREADS;
-            if ((q + 1) * LM_THREADS <= LM_PS || e < LM_PS) dst[e] = r[q];
+            if ((q + 1) * LM_THREADS <= LM_PS || e < LM_PS) dst[e] = (gok[q] && pok) ? r[q] : 0.0;
         }
     };
     // is this thread's cell c a row this launch relaxes in plane k?
@@ -434,22 +433,21 @@ __global__ __launch_bounds__(G2_THREADS) void lat_gs2(Gs2Args a) {
         goff[q] = (unsigned)(min(max(gj, 0), a.ny - 1) * a.nx + min(max(gi, 0), a.nx - 1));
     }
     auto load_plane = [&](int p, double (&r)[G2_LOADS]) {
-        const bool pok = p >= 0 && p < a.nz;
         const int64_t po = (int64_t)min(max(p, 0), a.nz - 1) * a.P;
 #pragma unroll
         for (int q = 0; q < G2_LOADS; ++q) {
             const bool done = g2_color(gi_[q], gj_[q], p) < a.c1;           // relaxed by an earlier launch of this sweep
             const double* const src = done ? a.xnew : a.xold;
-            const double v = src[po + goff[q]];
-            r[q] = (gok[q] && pok) ? v : 0.0;
+            r[q] = src[po + goff[q]];
         }
     };
-    auto store_plane = [&](int p, const double (&r)[G2_LOADS]) {
+    auto store_plane = [&](int p, const double (&r)[G2_LOADS]) {         // (zeros selected here, not behind the loads)
+        const bool pok = p >= 0 && p < a.nz;
         double* const dst = xs + ((p + 2 * G2_NS) % G2_NS) * G2_PS;        // (p >= -9)
 #pragma unroll
         for (int q = 0; q < G2_LOADS; ++q) {
             const int e = tid + q * G2_THREADS;
-            if ((q + 1) * G2_THREADS <= G2_PS || e < G2_PS) dst[e] = r[q];
+            if ((q + 1) * G2_THREADS <= G2_PS || e < G2_PS) dst[e] = (gok[q] && pok) ? r[q] : 0.0;
         }
     };
     // one row: the class's entries in stored order from LDS (wave-uniform class with an LDS copy) or from the global table
