@@ -30,6 +30,26 @@ template <bool NT> __global__ void k_copy(const d2* __restrict__ a, d2* __restri
         if (NT) __builtin_nontemporal_store(v, b + i); else b[i] = v;
     }
 }
+__global__ void k_read_flat(const d2* __restrict__ a, size_t n, double* out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) { const d2 v = a[i]; if (v.x + v.y == 1.2345) out[0] = v.x; }
+}
+__global__ void k_copy_flat(const d2* __restrict__ a, d2* __restrict__ b, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+__global__ void k_axpy_flat(const d2* __restrict__ x, const d2* __restrict__ f, d2* __restrict__ o, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) o[i] = x[i] + f[i];
+}
+// block b handles a contiguous chunk of `per` elements per thread-row (a tile-like order: long runs per workgroup)
+__global__ void k_axpy_chunk(const d2* __restrict__ x, const d2* __restrict__ f, d2* __restrict__ o, size_t n, size_t per) {
+    const size_t base = blockIdx.x * per * blockDim.x;
+    for (size_t t = 0; t < per; ++t) {
+        const size_t i = base + t * blockDim.x + threadIdx.x;
+        if (i < n) o[i] = x[i] + f[i];
+    }
+}
 // out = x + f (2 reads : 1 write), like a class-coded sweep without the stencil
 template <bool NT> __global__ void k_axpy(const d2* __restrict__ x, const d2* __restrict__ f, d2* __restrict__ o, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -77,6 +97,14 @@ int main(int argc, char** argv) {
         const unsigned g = (unsigned)((n + 255) / 256);
         time("write flat grid", B, [&] { hipLaunchKernelGGL(k_write_flat<false>, dim3(g), dim3(256), 0, 0, a, n); });
         time("write flat grid nt", B, [&] { hipLaunchKernelGGL(k_write_flat<true>, dim3(g), dim3(256), 0, 0, a, n); });
+        time("read flat grid", B, [&] { hipLaunchKernelGGL(k_read_flat, dim3(g), dim3(256), 0, 0, a, n, out); });
+        time("copy flat grid (r+w bytes)", 2 * B, [&] { hipLaunchKernelGGL(k_copy_flat, dim3(g), dim3(256), 0, 0, a, b, n); });
+        time("o = x + f flat grid (2r+1w bytes)", 3 * B, [&] { hipLaunchKernelGGL(k_axpy_flat, dim3(g), dim3(256), 0, 0, a, b, c, n); });
+        for (size_t per : {8, 64, 512}) {
+            char name[64]; snprintf(name, sizeof name, "o = x + f, %zu x 4 KiB per block (2r+1w)", per);
+            const unsigned gc = (unsigned)((n + per * 256 - 1) / (per * 256));
+            time(name, 3 * B, [&] { hipLaunchKernelGGL(k_axpy_chunk, dim3(gc), dim3(256), 0, 0, a, b, c, n, per); });
+        }
     }
     return 0;
 }
