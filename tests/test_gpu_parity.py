@@ -1082,6 +1082,24 @@ def test_shim_replays_the_captured_cycle(mg):
     assert mg._hierarchy().counters()["graphs_cached"] >= 1
 
 
+def test_prepare_cycle_only_moves_the_lazy_set_up_forward():
+    """`mg_prepare_cycle` builds what the first V-cycle would build lazily (direct coarsest solve and its validation,
+    colouring checks, work vectors): calling it -- once or twice, or not at all -- leaves the cycles bit for bit alike, and
+    the first cycle after it is already the captured one."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    out = []
+    for prepare in (0, 1, 2):
+        with DeviceHierarchy.synthetic(3, 1, 4, c=4, mu1=3, mu2=3) as h:
+            for _ in range(prepare):
+                h.prepare_cycle(4)
+            h.zero_vector(4, "v")
+            res = h.vcycle(4, 3, residuals=True)
+            out.append((np.asarray(res), h.get_vector(4, "v"), h.counters()))
+    for res, v, counters in out[1:]:
+        assert np.array_equal(res, out[0][0]) and np.array_equal(v, out[0][1])
+        assert counters["graphs_cached"] >= 1 and counters["graph_replays"] >= 1, counters
+
+
 def test_adhoc_contexts_are_bounded(mg):
     """Stand-alone contexts (norms of vectors of many lengths, transfers between many mesh pairs) live in one
     bounded LRU cache; `configure` / `initialize_problem` drop them."""
