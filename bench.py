@@ -8,10 +8,11 @@ Poisson hierarchy named by --config, device-resident from start to end (the hier
 right-hand side are generated in HBM before the timed region).  Default = BASELINE.json's headline
 workload: 3-D, 6 levels, N = 1024 elements per dimension (1025^3 unknowns), V(50,50), omega = 2/3 --
 the reference's shipped smoother parameters (Multigrid_prototype.py:42-46).  With N > 1 GPUs the
-same grid is split into slabs (strong scaling); launch as
+same grid is split into slabs (strong scaling); either launch as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N ...
-torch is used for that rendezvous only (RCCL id broadcast, barrier, max over ranks; gloo); the data
+or plainly as `python bench.py --gpus N`, which starts exactly that as a child process (before touching a GPU)
+and relays its line.  torch is used for that rendezvous only (RCCL id broadcast, barrier, max over ranks; gloo); the data
 path is libmg_hip.so + RCCL.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
@@ -115,9 +116,6 @@ class Rendezvous:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != gpus:
-            if self.world == 1 and gpus > 1:
-                raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run "
-                                 "(one rank per GPU)")
             raise SystemExit(f"--gpus {gpus} does not match WORLD_SIZE {self.world}")
         self.dist = None
         if self.world > 1:
@@ -322,8 +320,41 @@ def cpu_baseline(args):
     }
 
 
+def launch_own_ranks(gpus):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves -- as fresh child
+    processes (`python -m torch.distributed.run ... bench.py <same arguments>`), BEFORE this process has made any GPU
+    call (it never makes one) -- relay rank 0's JSON line and return the children's exit code.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                   # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:                         # the launcher and the ranks keep stdout for the one JSON line
+        text = raw.decode(errors="replace")
+        if text.lstrip().startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_own_ranks(args.gpus))
     p2 = args.config == "c5"
     if args.mu is None:
         args.mu = 2 if p2 else 50

@@ -439,6 +439,18 @@ void free_level(mg_context* c, Level& L) {
     ++c->epoch;
     drop_graphs(c);
     if (&L == &c->L[0]) free_direct(c);
+    // what the handle keeps sized for this level's geometry goes with it: the mass matrix and its work vector, the
+    // exact solution and the difference vector (a level that is set again may have another size)
+    if (c->mass_level >= 0 && &L == &c->L[c->mass_level]) {
+        vec_free(c, L, &c->mass_out);
+        c->mass_level = -1;
+        free_level(c, c->mass);
+    }
+    if (c->uexact_level >= 0 && &L == &c->L[c->uexact_level]) {
+        vec_free(c, L, &c->uexact);
+        vec_free(c, L, &c->diff);
+        c->uexact_level = -1;
+    }
     const size_t ell = (size_t)L.nslices * L.W * (WAVE * L.R);
     dev_free(c, L.vals, ell);
     dev_free(c, L.cols, ell);
@@ -3193,6 +3205,8 @@ int mg_set_mass_csr(mg_handle c, int level, int64_t n_rows, int64_t nnz, const v
     Level& L = c->L[level];
     if (n_rows != L.n_global) return fail("mass matrix has " + std::to_string(n_rows) + " rows, level has " + std::to_string(L.n_global));
     Level& M = c->mass;
+    // the work vector of mass_form is sized for the level the previous mass matrix belonged to
+    if (c->mass_out.raw && c->mass_level >= 0) vec_free(c, c->L[c->mass_level], &c->mass_out);
     free_level(c, M);
     c->mass_level = -1;
     M = Level();

@@ -39,3 +39,59 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def test_bench_starts_its_own_ranks_when_not_under_a_launcher(monkeypatch, capsys):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: the parent never touches a GPU, it starts
+    `python -m torch.distributed.run ... bench.py <same arguments>` as a child process, relays rank 0's JSON line and
+    returns the child's exit code (CPU: the child is replaced by a stub)."""
+    import io
+    import bench
+
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, stdout=None, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.BytesIO(b"NCCL version banner\n" + b'{"metric": "m", "value": 1.0, "n_gpus": 4}\n')
+
+        def wait(self):
+            return seen.get("rc", 0)
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert [l for l in out.out.splitlines() if l.strip()] == ['{"metric": "m", "value": 1.0, "n_gpus": 4}']
+    assert "NCCL version banner" in out.err
+    # a failing child: its exit code comes back, and a child that printed no line is a failure too
+    seen["rc"] = 3
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 3
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_starts_itself():
+    """`python bench.py --gpus 2` without a launcher, two ranks sharing the one GPU through the host-staged gloo
+    transport (the RCCL transport needs one GPU per rank): one JSON line, n_gpus 2, strong scaling."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3", "--transport", "gloo",
+                          "--mu", "2", "--steps", "2", "--warmup", "1", "--kernel-reps", "2"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("slab2")
+    assert d["residual_l2_after"] < d["rhs_l2"]

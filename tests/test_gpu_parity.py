@@ -128,9 +128,10 @@ def test_v_cycle_matches_reference(mg, name, with_dicts):
     A3, f = bag.A_jacobi_sp_dict[3], bag.b_dict[3]
     v = np.zeros_like(f)
     for k in (1, 2, 3):
-        v_in = v.copy()
-        v = mg.V_cycle_scheme(A3, v, f)
-        assert v.shape == (4225, 1) and np.array_equal(v_in, v_in)
+        v_in, v_before, f_before = v, v.copy(), f.copy()
+        v = mg.V_cycle_scheme(A3, v_in, f)
+        assert v.shape == (4225, 1) and v is not v_in
+        assert np.array_equal(v_in, v_before) and np.array_equal(f, f_before)   # inputs not mutated (multigrid.py:226-227)
         assert rel_l2(v, g[f"vcycle_iter{k}"]) <= TOL_ITER
         r = f - bag.A_sp_dict[3][0].dot(v)
         assert abs(np.linalg.norm(r) - g["vcycle_res_l2"][k - 1]) <= TOL_ITER * g["vcycle_res_l2"][k - 1]
@@ -1039,6 +1040,36 @@ def test_full_multigrid_keeps_its_norms_on_the_device(mg, tmp_path, monkeypatch)
     assert n2 > n1 + 2, counts
     assert (up1, down1) == (up2, down2), counts
     assert up1 <= 6 and down1 <= 2, counts
+
+
+def test_mass_matrix_can_move_to_another_level():
+    """`mg_set_mass_csr` on level 2, FMG in the mass norm, then on the (four times larger) level 3 and FMG again: the
+    work vector of the mass form must follow the level (it used to keep the first level's size: an out-of-bounds
+    device write through the public C ABI)."""
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    bag = poisson.make_hierarchy(2, 1, 3, c=4, mu0=2, mu1=4, mu2=4, seed=2)
+    gi = {l: L.grid_index for l, L in bag.levels.items()}
+    with DeviceHierarchy.from_bag(bag, dim=2, grid_index=gi) as dev:
+        for top, N in ((2, 16), (3, 32), (2, 16)):
+            lvl = bag.levels[top]
+            M = _p1_mass_matrix(lvl, N)
+            dev.set_mass(top, M)
+            dev.set_exact(top, lvl.exact())
+            for l in range(1, top):
+                dev.set_rhs_true(l, bag.b_dict[l])
+            dev.set_vector(top, "f", bag.b_dict[top])
+            res, err = dev.fmg(2, top_level=top, norm="mass", errors=True)
+            u = dev.get_vector(top, "v")
+            r = bag.b_dict[top] - bag.A_sp_dict[top][0].dot(u)
+            e = u - lvl.exact()
+            want_r = float(np.sqrt((r.T @ (M @ r)).item()))
+            want_e = float(np.sqrt((e.T @ (M @ e)).item()))
+            assert abs(res[-1] - want_r) <= 1e-9 * want_r + 1e-15
+            assert abs(err[-1] - want_e) <= 1e-9 * want_e + 1e-15
+        # a level that is set again drops what the handle kept for its old geometry
+        dev.set_level(2, bag.A_sp_dict[2][0], gi[2])
+        with pytest.raises(Exception):
+            dev.fmg(2, top_level=2, norm="mass")
 
 
 def test_full_multigrid_never_changes_norm_silently(mg, tmp_path, monkeypatch):
