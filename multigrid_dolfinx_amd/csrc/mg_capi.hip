@@ -5,6 +5,7 @@
 #include "mg_kernels.hip.h"
 #include "mg_direct.hip.h"
 #include "mg_jacobi2.hip.h"
+#include "mg_jacobik3d.hip.h"
 #include "mg_lattice.hip.h"
 
 #include <dlfcn.h>
@@ -253,6 +254,11 @@ struct mg_context {
     int fuse_plain_shape = 0;       // ... its launch shape: 0 = 12 waves x 1 line (no spills), 1 = 8 x 2, 2 = 16 x 1
     int fuse_plain = 2;             // the pass on the stored rows (no classes): 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's
     int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
+    int fuse_k = 4;                 // sweeps per pass of the class-coded K-sweep march (mg_jacobik3d.hip.h): 3..5; < 3: pairs only
+    int fuse_k_shape = 0;           // ... its tile: 0 = 128 x 24 cells (12 waves x 2 lines), 1 = 64 x 48 (12 waves x 4 lines),
+                                    // 2 = 128 x 24 (8 waves x 3 lines, 256 registers)
+    int fuse_k_segments = 0;        // ... plane segments per tile (0: chosen from the item count)
+    int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
     int fuse_wi = 0;                // experiments: cells per tile line with a second sweep (0: chosen per level)
@@ -1144,6 +1150,72 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
 }
 
+// K sweeps per pass (mg_jacobik3d.hip.h): whole seven-point levels with row classes that use the two-sweep pass.
+bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
+    if (c->fuse_k < 3 || !L.cls || !c->fuse_classes || !L.replicated) return false;
+    return fused_sweeps_ok(c, L, ignore_size) && L.g.nk >= 8;
+}
+
+template <int K, int NW, int LPW, int M, bool DPP>
+int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
+    constexpr int EX = 64 * M, EY = NW * LPW, WI = EX - 2 * K, HY = EY - 2 * K + 2;
+    a.ntx = (a.nx + WI - 1) / WI;
+    a.nty = (a.ny + HY - 1) / HY;
+    const int64_t ntile = (int64_t)a.ntx * a.nty;
+    // plane segments: rounds of one resident workgroup per CU, each item paying 2K steps of warm-up (which do about
+    // two thirds of a step's work)
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    int best = 1;
+    double best_cost = 1e300;
+    for (int n = 1; n <= std::max(1, a.nz / 16); ++n) {
+        const double cost = (double)((ntile * n + cus - 1) / cus) * ((a.nz + n - 1) / n + 1.4 * K);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    if (c->fuse_k_segments > 0) best = std::min(c->fuse_k_segments, a.nz);
+    a.seglen = (a.nz + best - 1) / best;
+    const int nseg = (a.nz + a.seglen - 1) / a.seglen;
+    const int64_t items = ntile * nseg;
+    if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
+    a.nitems = (unsigned)items;
+    a.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
+    const int64_t group = 8 * (int64_t)a.xcd_chunk;
+    const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
+    constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M>();
+    static_assert(lds <= 160 * 1024, "one CU's LDS");
+    void (*const kern[2])(JK3Args) = {sdia_jacobikc<K, NW, LPW, M, DPP>, sdia_jacobikc_finest<K, NW, LPW, M, DPP>};
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
+    hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int K>
+int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest) {
+    if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false>(c, a, finest);      // (experiment: -1 / +1 neighbours through LDS)
+    switch (c->fuse_k_shape) {
+        case 1: return launch_jacobikc_t<K, 12, 4, 1, true>(c, a, finest);
+        case 2: return launch_jacobikc_t<K, 8, 3, 2, true>(c, a, finest);
+        default: return launch_jacobikc_t<K, 12, 2, 2, true>(c, a, finest);
+    }
+}
+
+// out = K Jacobi sweeps applied to x (3 <= K <= 5), whole levels
+int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, const double* f_rows, double* out_rows) {
+    JK3Args a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead; a.ncls = L.ncls; a.cmain = L.cmain;
+    for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+    a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
+    a.plo = a.phi = 0;
+    const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
+    switch (K) {
+        case 3: return launch_jacobikc_k<3>(c, a, finest);
+        case 4: return launch_jacobikc_k<4>(c, a, finest);
+        case 5: return launch_jacobikc_k<5>(c, a, finest);
+        default: return fail("sweeps per pass must be in 3..5");
+    }
+}
+
 // Is lattice_color(COLOR_LATTICE9) a valid Gauss-Seidel colouring of the level's matrix?  (structure of the stored
 // non-zeros, in whatever format the level has)
 int check_coloring(mg_context* c, Level& L) {
@@ -1365,6 +1437,19 @@ int smooth(mg_context* c, int level, int nw) {
     if (fused && nw > 1) {
         if (dist) MG_TRY(vec_alloc(c, L, &L.sw));
         plan = jacobi2_plan(c, L, dist, lo_end * S + L.g.plane + L.g.nx + 2);
+    }
+    if (!dist && fused && nw >= 3 && sweepsk_ok(c, L)) {
+        // whole levels: K sweeps per pass while that leaves no single sweep over (50 = 12 x 4 + 2, 7 = 4 + 3, 5 = 3 + 2)
+        const int kmax = std::min(c->fuse_k, 5);
+        int left = nw;
+        while (left >= 3) {
+            int k = left >= kmax + 2 || left == kmax ? kmax : left == kmax + 1 ? kmax - 1 : left;
+            if (k < 3) break;
+            MG_TRY(launch_jacobikc(c, L, k, L.v.rows, L.f.rows, L.v2.rows));
+            std::swap(L.v, L.v2);
+            left -= k;
+        }
+        nw = left;
     }
     for (int s = 0; s < nw; ++s) {
         if (fused && s + 1 < nw) {
@@ -2584,6 +2669,17 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_plain") {
         if (value != 1 && value != 2) return fail("fuse_plain must be 1 or 2");
         c->fuse_plain = (int)value;
+    } else if (k == "fuse_k") {
+        if (value < 0 || value > 5) return fail("fuse_k must be in 0..5 (below 3: pairs of sweeps only)");
+        c->fuse_k = (int)value;
+    } else if (k == "fuse_k_shape") {
+        if (value < 0 || value > 2) return fail("fuse_k_shape must be 0..2");
+        c->fuse_k_shape = (int)value;
+    } else if (k == "fuse_k_dpp") {
+        c->fuse_k_dpp = value != 0;
+    } else if (k == "fuse_k_segments") {
+        if (value < 0) return fail("fuse_k_segments must be >= 0");
+        c->fuse_k_segments = (int)value;
     } else if (k == "fuse_classes") {
         c->fuse_classes = value != 0;
     } else if (k == "fuse_nontemporal") {
@@ -3354,6 +3450,10 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             if (!fused_sweeps_ok(c, L, k == "jacobi2!")) return fail("level does not use the two-sweep kernel");
             const J2Plan plan = jacobi2_plan(c, L, false, 0);
             return launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows);
+        }
+        if (k == "jacobik3" || k == "jacobik3!") {     // K = fuse_k sweeps per pass on a whole class-coded 3-D level
+            if (!sweepsk_ok(c, L, k == "jacobik3!")) return fail("level does not use the K-sweep pass");
+            return launch_jacobikc(c, L, std::min(c->fuse_k, 5), L.v.rows, L.f.rows, L.v2.rows);
         }
         if (k == "jacobi_small") {           // all mu1 sweeps of a small level in one launch
             if (!small_level_ok(c, L) || c->mu1 < 2) return fail("level does not use the one-launch smoother");

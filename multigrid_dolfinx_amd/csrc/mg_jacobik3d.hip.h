@@ -1,0 +1,461 @@
+// K weighted-Jacobi sweeps in one pass over HBM (K = 3, 4, 5) on class-coded 3-D seven-point levels.
+//
+// multigrid.py:223-228 runs mu = 50 identical sweeps in a row.  The two-sweep pass (mg_jacobi2.hip.h) already streams
+// its 25 bytes per row at the rate the memory system gives a plane march, so the only lever left is bytes per SWEEP:
+// here a workgroup carries K sweeps through the planes at once and a pass costs one read of x, f and the class byte
+// and one write of the result per K sweeps (plus the tile rims, which grow with K: a tile loads EX x (EY + 2) cells of
+// a plane and stores (EX - 2K) x (EY - 2K + 2)).
+//
+// The march.  "Level" t is the iterate after t sweeps (level 0 = x).  A thread owns NC cells of the tile; at step k
+// the workgroup FINISHES plane k+K-t of level t for t = 1 .. K (level K of plane k is the result) and STARTS the plane
+// above it.  A row's sum is accumulated in the order of the one-sweep kernels, -P, -nx, -1, 0, +1, +nx, +P:
+//   phase A  (registers only)  the level-(t-1) value of plane k+K-t+1 has just been finished (or, level 0, arrived
+//            from memory): it is the missing +P term of level t in plane k+K-t, whose result is thereby complete --
+//            and in turn the missing term of level t+1 one plane below: the K finishes chain through registers.  The
+//            value a cell relaxes (its own previous-level value, the diagonal operand) is read back from the cell's own
+//            slot of the level's LDS image, which then takes the new plane.  The next plane's sum starts with its -P
+//            term, that same read-back value.
+//   barrier
+//   phase B  the in-plane terms (-nx, -1, 0, +1, +nx) of the planes started in phase A.  A thread reads its own cells'
+//            values back from the images and the line below / above its lines; the -1 / +1 neighbours are its own
+//            values of the neighbouring lanes (DPP wave rotates; the lane at a 64-cell seam takes the rotated value of
+//            the cell next door), the +-nx neighbours between a thread's own lines are its own registers.
+//   barrier
+// so per cell and level there are K partial sums in registers and ONE plane image in LDS -- K (EY+2) x EX images in
+// all --, not three planes of every level, and per cell, level and step the LDS sees one write and three reads.  f is
+// needed by every level of a plane: a ring of K values per cell, the newest arriving from memory a step before its first use; class bytes are packed four cells to a register.  The
+// loads of plane k+K+1 are issued right after phase A has consumed plane k+K's registers and are in flight through
+// phase B and both barriers.
+// A wave whose cells of the planes k .. k+K all carry the level's most frequent class (the interior stencil), in a
+// step whose planes all exist, runs straight-line code with the entries in scalar registers; other waves (next to the
+// boundary, first / last planes) take the general path: per cell group either the scalar entries or the class table.
+// Everything is done in ROW space like the other passes (cell <-> row whether or not it wraps around a grid line; rows
+// outside the level are zeros at every level), with the same fma chain and the same IEEE division as sdia_cls_body:
+// bit-identical to K single sweeps.  Out-of-grid cells that the tile clamps (lines beyond ny + 1 or below -2, cells
+// past the end of a grid line) hold finite, wrong values; they reach grid rows only through couplings that do not
+// exist (stored zeros), so no result depends on them.
+//
+// Slabs: with K halo planes of x (and K - 1 of f and the classes) on either side a rank relaxes level t on the planes
+// [-(K-t), nz + (K-t)) of its neighbours too (plo / phi), so K sweeps need ONE exchange and no boundary chain.
+#pragma once
+#include "mg_jacobi2.hip.h"
+#include <type_traits>
+
+namespace mgk {
+
+struct JK3Args {
+    const double* x;            // row-based source iterate, zero slack (vec_reach) on both sides
+    const double* f;            // row-based
+    double* out;                // row-based, != x
+    const unsigned char* cls;   // class of row r is cls[r + clead]
+    const double* ctab;         // ctab[class][CLS_W]: the row's seven entries in column order
+    int64_t clead, P;
+    int ncls, cmain;
+    double cm[8];               // entries of the most frequent class (scalar registers)
+    double omega;
+    int nx, ny, nz;             // nz: owned planes
+    int plo, phi;               // halo planes below / above whose rows exist on a neighbour (0: the level ends here)
+    int ntx, nty, seglen;
+    unsigned nitems, xcd_chunk;
+};
+
+template <int K, int NW, int LPW, int M> constexpr size_t jk3_lds_bytes() {
+    return sizeof(double) * (256 * CLS_W + (size_t)K * (NW * LPW + 2) * (64 * M) + 2 * (64 * M + 2));
+}
+
+// the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
+__device__ __forceinline__ double jk3_from_west(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xF, 0xF, false);     // wave_ror:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double jk3_from_east(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xF, 0xF, false);     // wave_rol:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, int NW, int LPW, int M, bool DPP>
+__device__ __forceinline__ void jk3_body(const JK3Args& a) {
+    constexpr int EX = 64 * M, EY = NW * LPW, NC = M * LPW, IMG = (EY + 2) * EX, CW = (NC + 3) / 4;
+    constexpr int WI = EX - 2 * K, HY = EY - 2 * K + 2;       // cells per line / lines of a tile that get all K sweeps
+    static_assert(NC * (K + 1) <= 64, "the fast-path flags live in one scalar register pair");
+    static_assert(WI > 0 && HY > 0, "tile too small for K sweeps");
+    extern __shared__ double j2_smem[];
+    double* const sT = j2_smem;                               // 256 x 8   entries of the row classes, [7] = omega / diagonal
+    double* const sI = sT + 256 * CLS_W + (EX + 2);           // K x (EY+2) x EX   one plane of level t, origin (0,-1)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    unsigned id;
+    {
+        const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3, ch = a.xcd_chunk;
+        id = ((j / ch) * 8u + xcd) * ch + (j % ch);
+    }
+    if (id >= a.nitems) return;
+    const unsigned ntile = (unsigned)(a.ntx * a.nty);
+    const int seg = (int)(id / ntile);
+    const unsigned tt = id % ntile;
+    const int tiy = (int)(tt / (unsigned)a.ntx), tix = (int)(tt % (unsigned)a.ntx);
+    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    if (z1 <= z0) return;
+    const int tx0 = tix * WI - K, ty0 = tiy * HY - (K - 1);   // grid position of cell (0, 0)
+
+    {
+        const int nt = a.ncls * CLS_W;
+        for (int i = threadIdx.x; i < nt; i += NW * WAVE) {
+            double v = a.ctab[i];
+            if ((i & (CLS_W - 1)) == CLS_W - 1) {
+                const double d = a.ctab[i - 4];
+                v = a.omega * (1.0 / (d != 0.0 ? d : 1.0));
+            }
+            sT[i] = v;
+        }
+        for (int i = threadIdx.x; i < K * IMG + 2 * (EX + 2); i += NW * WAVE) sT[256 * CLS_W + i] = 0.0;
+    }
+    const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
+    const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    const int cmain = a.cmain;
+
+    // cell c = l*M + r of this thread: ex = lane + 64 r, ey = wave*LPW + l
+    const int ey0 = wave * LPW;
+    const int lw0 = (ey0 + 1) * EX + lane;
+    auto lwof = [&](int c) -> int { return (c / M) * EX + 64 * (c % M); };      // cell c relative to cell 0
+    // cell 0 in the images 0, 1 / 2, 3 / 4: one address register per pair, so that every LDS access of the march is
+    // `register + 16-bit immediate` (the images span more than 64 KB; left alone the compiler keeps an address per
+    // cell and image)
+    int ibase[(K + 1) / 2];     // (element offsets from sI; the pin keeps the compiler from folding them back into one per access)
+#pragma unroll
+    for (int q = 0; q < (K + 1) / 2; ++q) {
+        ibase[q] = 2 * q * IMG + lw0;
+        asm volatile("" : "+v"(ibase[q]));
+    }
+    auto image = [&](int t) -> double* { return sI + ibase[t >> 1] + (t & 1) * IMG; };  // level t's plane, at cell 0
+    unsigned inT = 0;           // bit c: this lane's cell c gets all K sweeps and lies on the grid
+    const int64_t rb0 = (int64_t)(ty0 + ey0) * a.nx + (tx0 + lane);
+    auto rowof = [&](int c) -> int64_t { return rb0 + (int64_t)(c / M) * a.nx + 64 * (c % M); };
+    // the row of cell c in plane p exists  <=>  the level's plane range holds p + sh(c), sh = -1, 0, +1 (two bits per cell)
+    unsigned shw = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ex = lane + 64 * (c % M), ey = ey0 + c / M;
+        if (ex >= K && ex < EX - K && ey >= K - 1 && ey <= EY - K && tx0 + ex < a.nx && ty0 + ey < a.ny) inT |= 1u << c;
+        const int64_t r = rowof(c);
+        shw |= (r < 0 ? 0u : (r >= a.P ? 2u : 1u)) << (2 * c);
+    }
+    auto shof = [&](int c) -> int { return (int)((shw >> (2 * c)) & 3u) - 1; };
+    const bool wlo = wave == 0, whi = wave == NW - 1;
+
+    // Addresses: `uniform base of the plane + a byte offset fixed for the whole march` (see j2c_body).  Lines are
+    // clamped to [-2, ny + 1], cells past the end of their grid line to the cell behind it, planes to the slack planes.
+    const int bias = 2 * a.nx + K + 2;
+    const int xcl = a.nx + 1 - tx0;
+    unsigned eo[NC], eor[M];    // byte offsets of the cells' doubles (>> 3: of their class bytes)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        eo[c] = 8u * (unsigned)(min(max(ty0 + ey0 + c / M, -2), a.ny + 1) * a.nx + tx0 + min(lane + 64 * (c % M), xcl) + bias);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        eor[r] = 8u * (unsigned)((wlo ? max(ty0 - 1, -2) : min(ty0 + EY, a.ny + 1)) * a.nx + tx0 + min(lane + 64 * r, xcl) + bias);
+    const unsigned char* const clsb = a.cls + a.clead - bias;
+    const double* const xb0 = a.x - bias;
+    const double* const fb0 = a.f - bias;
+    auto sbase = [](const void* p) -> gcptr_t {
+        const unsigned long long u = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+        return (gcptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    // (the pins keep the 32-bit offsets from being widened once and for all outside the loop: `scalar base + 32-bit
+    //  register offset` is an addressing mode, a 64-bit register pair per cell is not)
+    auto ldd = [](gcptr_t b, unsigned e8) -> double {
+        asm volatile("" : "+v"(e8));
+        return *(const __attribute__((address_space(1))) double*)(b + e8);
+    };
+    auto ldc = [](gcptr_t b, unsigned e8) -> int {
+        unsigned e = e8 >> 3;
+        asm volatile("" : "+v"(e));
+        return *(const __attribute__((address_space(1))) unsigned char*)(b + e);
+    };
+    const int pmin = -a.plo - 1, pmax = a.nz + a.phi;
+
+    // registers per cell: K partial sums; f of the planes k .. k+K-1; x, f and the class of the plane that arrives
+    double acc[K][NC], fr[K][NC], X[NC], hy[M];
+    int C[NC];
+    unsigned cw[K + 1][CW];     // class bytes of the planes k .. k+K, four cells to a register
+    unsigned long long fast = 0;        // wave-uniform; bit j*NC + c: all 64 cells c of plane k+j are of class cmain
+    constexpr unsigned long long ALLFAST = (NC * (K + 1) == 64) ? ~0ull : ((1ull << (NC * (K + 1))) - 1ull);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) acc[t][c] = fr[t][c] = 0.0;
+        X[c] = 0.0;
+        C[c] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j <= K; ++j)
+#pragma unroll
+        for (int q = 0; q < CW; ++q) cw[j][q] = 0u;
+#pragma unroll
+    for (int r = 0; r < M; ++r) hy[r] = 0.0;
+
+    // x and the classes of `plane`, f of the plane below it -- which a step needs one step later: it arrives in the
+    // slot of the ring that has just become free
+    auto load_plane = [&](const int plane) {
+        const int64_t o = (int64_t)min(max(plane, pmin), pmax) * a.P;
+        const gcptr_t cb = sbase(clsb + o);
+        const gcptr_t fb = sbase(fb0 + (int64_t)min(max(plane - 1, pmin), pmax) * a.P);
+        const gcptr_t xb = sbase(xb0 + o);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            X[c] = ldd(xb, eo[c]);
+            C[c] = ldc(cb, eo[c]);
+            fr[K - 1][c] = ldd(fb, eo[c]);
+        }
+        if (wlo || whi) {
+#pragma unroll
+            for (int r = 0; r < M; ++r) hy[r] = ldd(xb, eor[r]);
+        }
+    };
+    auto cls_of = [&](int j, int c) -> int { return (int)((cw[j][c >> 2] >> (8 * (c & 3))) & 255u); };
+    // (general form: extracted anew at every use -- kept, the table addresses of all cells and ring planes cost 20 registers)
+    auto cls_now = [&](int j, int c) -> int {
+        unsigned w = cw[j][c >> 2];
+        asm volatile("" : "+v"(w));
+        return (int)((w >> (8 * (c & 3))) & 255u);
+    };
+    int k_plane = 0;            // the step: plane whose result it stores, whether it stores, the plane's base in `out`
+    bool k_store = false;
+    __attribute__((address_space(1))) char* k_out = nullptr;
+    // (a cell that stores is not clamped: its byte offset is its row's)
+    auto store = [&](int c, double v) {
+        unsigned e8 = eo[c];
+        asm volatile("" : "+v"(e8));
+        *(__attribute__((address_space(1))) double*)(k_out + e8) = v;
+    };
+    // plane range of level t (rows outside it are zeros)
+    int lo_t[K + 1], n_t[K + 1];
+#pragma unroll
+    for (int t = 1; t <= K; ++t) {
+        lo_t[t] = -min(a.plo, K - t);
+        n_t[t] = a.nz + min(a.phi, K - t) - lo_t[t];
+    }
+
+    // ---- the three forms of a step (chosen per wave and step; all of them read and write the images alike) ----
+    // Straight-line form.  COL = false: every cell has the interior stencil, entries in scalar registers.  COL = true:
+    // a cell's class depends on its lane only (tile columns along the x boundary, away from the other boundaries): the
+    // entries of the lane's row come from the class table once per cell group and phase.
+    auto phase_a_fast = [&](auto col_tag) {
+        constexpr bool COL = decltype(col_tag)::value;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            double k0 = m0, k6 = m6, kcf = mcf;
+            if constexpr (COL) {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, r));
+                const dvec2_t t01 = tr[0], t67 = tr[3];
+                k0 = t01.x; k6 = t67.x; kcf = t67.y;
+            }
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) {
+                const int c = l * M + r, iw = lwof(c);
+                double nw = X[c];
+#pragma unroll
+                for (int t = 1; t <= K; ++t) {
+                    double* const img = image(t - 1);
+                    const double wd = img[iw];
+                    const double s = fma(k6, nw, acc[t - 1][c]);      // +P
+                    const double o = wd + kcf * (fr[K - t][c] - s);
+                    acc[t - 1][c] = fma(k0, wd, 0.0);                 // -P of the plane above
+                    img[iw] = nw;
+                    nw = o;
+                }
+                if (k_store && (inT >> c & 1u)) store(c, nw);
+            }
+        }
+    };
+    auto phase_b_fast = [&](auto col_tag) {
+        constexpr bool COL = decltype(col_tag)::value;
+        double k1[M], k2[M], k3[M], k4[M], k5[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            k1[r] = m1; k2[r] = m2; k3[r] = m3; k4[r] = m4; k5[r] = m5;
+            if constexpr (COL) {
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, r));
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
+                k1[r] = t01.y; k2[r] = t23.x; k3[r] = t23.y; k4[r] = t45.x; k5[r] = t45.y;
+            }
+        }
+#pragma unroll
+        for (int t = 1; t <= K; ++t) {
+            const double* const img = image(t - 1);
+            double v[LPW][M], ys[M], yn[M];
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                ys[r] = img[-EX + 64 * r];
+#pragma unroll
+                for (int l = 0; l < LPW; ++l) v[l][r] = img[l * EX + 64 * r];
+                yn[r] = img[LPW * EX + 64 * r];
+            }
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) {
+                double yw[M], ye[M];
+                if constexpr (DPP) {
+                    double fw[M], fe[M];
+#pragma unroll
+                    for (int r = 0; r < M; ++r) { fw[r] = jk3_from_west(v[l][r]); fe[r] = jk3_from_east(v[l][r]); }
+#pragma unroll
+                    for (int r = 0; r < M; ++r) {
+                        yw[r] = (r > 0 && lane == 0) ? fw[r > 0 ? r - 1 : 0] : fw[r];
+                        ye[r] = (r + 1 < M && lane == 63) ? fe[r + 1 < M ? r + 1 : r] : fe[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < M; ++r) {
+                        yw[r] = img[l * EX + 64 * r - 1];
+                        ye[r] = img[l * EX + 64 * r + 1];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < M; ++r) {
+                    const int c = l * M + r;
+                    double s = acc[t - 1][c];
+                    s = fma(k1[r], l > 0 ? v[l > 0 ? l - 1 : 0][r] : ys[r], s);
+                    s = fma(k2[r], yw[r], s);
+                    s = fma(k3[r], v[l][r], s);
+                    s = fma(k4[r], ye[r], s);
+                    s = fma(k5[r], l + 1 < LPW ? v[l + 1 < LPW ? l + 1 : l][r] : yn[r], s);
+                    acc[t - 1][c] = s;
+                }
+            }
+        }
+    };
+    // General form: every cell's entries from the class table, rows outside the level masked to zero.
+    auto phase_a_general = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = lwof(c);
+            double nw = X[c];
+            int pc = k_plane + shof(c);
+            asm volatile("" : "+v"(pc));            // (one register per cell and step, not one per cell and level for the whole march)
+#pragma unroll
+            for (int t = 1; t <= K; ++t) {
+                const int j = K - t;                                  // ring index of the plane being finished
+                double* const img = image(t - 1);
+                const double wd = img[iw];
+                const dvec2_t t67 = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_now(j, c))[3];
+                const dvec2_t t01 = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_now(j + 1, c))[0];
+                const double s = fma(t67.x, nw, acc[t - 1][c]);
+                double o = wd + t67.y * (fr[j][c] - s);
+                o = (unsigned)(pc + j - lo_t[t]) < (unsigned)n_t[t] ? o : 0.0;
+                acc[t - 1][c] = fma(t01.x, wd, 0.0);
+                img[iw] = nw;
+                nw = o;
+                __builtin_amdgcn_sched_barrier(0);      // (rare path: one cell and level at a time keeps it out of the
+                                                        //  register budget of the straight-line forms)
+            }
+            if (k_store && (inT >> c & 1u)) store(c, nw);
+        }
+    };
+    auto phase_b_general = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = lwof(c);
+#pragma unroll
+            for (int t = 1; t <= K; ++t) {
+                const double* const img = image(t - 1);
+                const double ys = img[iw - EX], yw = img[iw - 1], yd = img[iw], ye = img[iw + 1], yn = img[iw + EX];
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_now(K - t, c));
+                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
+                double s = acc[t - 1][c];
+                s = fma(t01.y, ys, s);
+                s = fma(t23.x, yw, s);
+                s = fma(t23.y, yd, s);
+                s = fma(t45.x, ye, s);
+                s = fma(t45.y, yn, s);
+                acc[t - 1][c] = s;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    load_plane(z0 - K);
+    __syncthreads();
+
+    for (int k = z0 - 2 * K; k < z1; ++k) {
+        k_plane = k; k_store = k >= z0;
+        {
+            const unsigned long long u = (unsigned long long)(a.out - bias + (int64_t)k * a.P);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+            k_out = (__attribute__((address_space(1))) char*)(((unsigned long long)hi << 32) | lo);
+        }
+        // ---- the plane k+K has arrived: its classes join the ring ----
+        {
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < CW; ++q) cw[K][q] = 0u;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                cw[K][c >> 2] |= (unsigned)C[c] << (8 * (c & 3));
+                if (__builtin_amdgcn_readfirstlane((int)(__ballot(C[c] != cmain) == 0ull))) m |= 1u << c;
+            }
+            fast |= (unsigned long long)m << (K * NC);
+        }
+        // which form: 0 = interior stencil everywhere in this wave's cells of the planes k .. k+K, 1 = classes that depend on
+        // the lane only -- both only where every row the step touches exists (planes k-1 .. k+K+1 through sh) --, 2 = general
+        int form = 2;
+        if (k >= 1 && k + K + 1 < a.nz) {
+            if (fast == ALLFAST) {
+                form = 0;
+            } else {
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j <= K; ++j)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) same = same && cls_of(j, c) == cls_of(0, c % M);
+                if (__builtin_amdgcn_readfirstlane((int)(__ballot(!same) == 0ull))) form = 1;
+            }
+        }
+        // ---- phase A: finish plane k+K-t of level t, t = 1 .. K; start the plane above it ----
+        if (form == 0) phase_a_fast(std::false_type{});
+        else if (form == 1) phase_a_fast(std::true_type{});
+        else phase_a_general();
+        if (wlo || whi) {
+            double* const ring = image(0) + (wlo ? -EX : LPW * EX);
+#pragma unroll
+            for (int r = 0; r < M; ++r) ring[64 * r] = hy[r];
+        }
+        // ---- the rings move on; the loads of the next plane go out ----
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j + 1 < K; ++j) fr[j][c] = fr[j + 1][c];
+            asm volatile("" : "+v"(fr[K - 2][c]));
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) cw[j][q] = cw[j + 1][q];
+        fast >>= NC;
+        load_plane(k + K + 1);
+        __syncthreads();
+        // ---- phase B: the in-plane terms of the planes started above (ring index K - t of the moved ring) ----
+        if (form == 0) phase_b_fast(std::false_type{});
+        else if (form == 1) phase_b_fast(std::true_type{});
+        else phase_b_general();
+        __syncthreads();
+    }
+}
+
+template <int K, int NW, int LPW, int M, bool DPP>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobikc(JK3Args a) {
+    jk3_body<K, NW, LPW, M, DPP>(a);
+}
+
+// (its own symbol for the finest level, so that profiler summaries list the dominant launches apart)
+template <int K, int NW, int LPW, int M, bool DPP>
+__global__ __launch_bounds__(NW * WAVE) void sdia_jacobikc_finest(JK3Args a) {
+    jk3_body<K, NW, LPW, M, DPP>(a);
+}
+
+}  // namespace mgk

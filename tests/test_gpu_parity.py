@@ -1151,10 +1151,18 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
-    variants = [dict(fuse_sweeps=0, fuse_small=0), dict(), dict(fuse_sweeps=0), dict(fuse_segments=1), dict(fuse_segments=3), dict(fuse_classes=0), dict(fuse_classes=0, fuse_plain_shape=1), dict(fuse_classes=0, fuse_plain_shape=2, fuse_segments=3),
-                dict(fuse_classes=0, fuse_plain=1), dict(fuse_shape=0), dict(fuse_shape=3), dict(fuse_shape=2, fuse_segments=2),
+    # (fuse_k=0: pairs of sweeps only, the two-sweep pass; fuse_k=3..5: the K-sweep march of mg_jacobik3d.hip.h in its
+    #  three tile shapes, with and without the DPP neighbour exchange, with one / several plane segments)
+    variants = [dict(fuse_sweeps=0, fuse_small=0), dict(), dict(fuse_sweeps=0), dict(fuse_k=0), dict(fuse_k=0, fuse_segments=1),
+                dict(fuse_k=0, fuse_segments=3), dict(fuse_classes=0), dict(fuse_classes=0, fuse_plain_shape=1),
+                dict(fuse_classes=0, fuse_plain_shape=2, fuse_segments=3),
+                dict(fuse_classes=0, fuse_plain=1), dict(fuse_k=0, fuse_shape=0), dict(fuse_k=0, fuse_shape=3),
+                dict(fuse_k=0, fuse_shape=2, fuse_segments=2),
                 dict(fuse_segments=5, fuse_nontemporal=1, fuse_classes=0), dict(rows_per_lane=1),
-                dict(rows_per_lane=4, fuse_segments=2), dict(rows_per_lane=1, row_classes=0)]
+                dict(rows_per_lane=4, fuse_segments=2), dict(rows_per_lane=1, row_classes=0),
+                dict(fuse_k=3), dict(fuse_k=4, fuse_k_segments=1), dict(fuse_k=5, fuse_k_segments=3), dict(fuse_k=4, fuse_k_shape=1),
+                dict(fuse_k=5, fuse_k_shape=1, fuse_k_segments=2), dict(fuse_k=4, fuse_k_shape=2), dict(fuse_k=3, fuse_k_shape=2, fuse_k_segments=4),
+                dict(fuse_k=4, fuse_k_dpp=0), dict(fuse_k=3, fuse_k_dpp=0, fuse_k_segments=2)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
@@ -1172,7 +1180,7 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
                 if (level, "v") not in want:
                     want[level, "v"] = rng.standard_normal(n)
                     want[level, "f"] = rng.standard_normal(n)
-                for nw in (2, 3, 6):
+                for nw in (2, 3, 4, 5, 6, 9):
                     dev.set_vector(level, "v", want[level, "v"])
                     dev.set_vector(level, "f", want[level, "f"])
                     dev.smooth(level, nw)
