@@ -255,9 +255,12 @@ struct mg_context {
     int fuse_plain = 2;             // the pass on the stored rows (no classes): 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's
     int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
     int fuse_k = 4;                 // sweeps per pass of the class-coded K-sweep march (mg_jacobik3d.hip.h): 3..5; < 3: pairs only
-    int fuse_k_shape = 0;           // ... its tile: 0 = 128 x 24 cells (12 waves x 2 lines), 1 = 64 x 48 (12 waves x 4 lines),
-                                    // 2 = 128 x 24 (8 waves x 3 lines, 256 registers)
+    int fuse_k_shape = 1;           // ... its tile: 0 = 128 x 24 cells (12 waves x 2 lines), 1 = 64 x 48 (12 waves x 4 lines; measured best),
+                                    // 2 = 128 x 24 (8 waves x 3 lines, 256 registers), 3 .. 5 = 64 x 24 by 6 / 8 / 4 waves, two workgroups per CU
     int fuse_k_segments = 0;        // ... plane segments per tile (0: chosen from the item count)
+    int timing_force_form = -1;     // mg_time_kernel("jacobik3:formN"): every step of the K-sweep pass in one form (wrong results; how fast
+                                    // each form is by itself)
+    int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
     int fuse_shape = 1;             // launch shape of the class-coded pass (launch_jacobi2); 1 measured best
@@ -1156,7 +1159,7 @@ bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     return fused_sweeps_ok(c, L, ignore_size) && L.g.nk >= 8;
 }
 
-template <int K, int NW, int LPW, int M, bool DPP>
+template <int K, int NW, int LPW, int M, bool DPP, int PF = 1, int WPE = (NW == 12 ? 3 : 2), int TR = 256>
 int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
     constexpr int EX = 64 * M, EY = NW * LPW, WI = EX - 2 * K, HY = EY - 2 * K + 2;
     a.ntx = (a.nx + WI - 1) / WI;
@@ -1164,7 +1167,10 @@ int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
     const int64_t ntile = (int64_t)a.ntx * a.nty;
     // plane segments: rounds of one resident workgroup per CU, each item paying 2K steps of warm-up (which do about
     // two thirds of a step's work)
-    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M, TR>();
+    static_assert(lds <= 160 * 1024, "one CU's LDS");
+    // (resident workgroups per CU: by LDS and by waves per SIMD)
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount) * (int64_t)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(4 * WPE / NW)));
     int best = 1;
     double best_cost = 1e300;
     for (int n = 1; n <= std::max(1, a.nz / 16); ++n) {
@@ -1180,23 +1186,36 @@ int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
     a.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
     const int64_t group = 8 * (int64_t)a.xcd_chunk;
     const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
-    constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M>();
-    static_assert(lds <= 160 * 1024, "one CU's LDS");
-    void (*const kern[2])(JK3Args) = {sdia_jacobikc<K, NW, LPW, M, DPP>, sdia_jacobikc_finest<K, NW, LPW, M, DPP>};
+    if (a.ncls > TR) return fail("more row classes than this tile shape keeps in LDS");
+    void (*const kern[2])(JK3Args) = {sdia_jacobikc<K, NW, LPW, M, DPP, PF, WPE, TR>, sdia_jacobikc_finest<K, NW, LPW, M, DPP, PF, WPE, TR>};
     MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
     hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+template <int K, int PF>
+int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest) {
+    if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false, PF>(c, a, finest);     // (experiment: -1 / +1 neighbours through LDS)
+    // shapes 3..5: 64 x 24 tiles, two workgroups per CU (class table of 64 rows); levels with more classes take shape 1
+    const int shape = c->fuse_k_shape >= 3 && a.ncls > 64 ? 1 : c->fuse_k_shape;
+    switch (shape) {
+        case 1: return launch_jacobikc_t<K, 12, 4, 1, true, PF>(c, a, finest);
+        case 2: return launch_jacobikc_t<K, 8, 3, 2, true, PF>(c, a, finest);
+        case 3: return launch_jacobikc_t<K, 6, 4, 1, true, PF, 3, 64>(c, a, finest);
+        case 4: return launch_jacobikc_t<K, 8, 3, 1, true, PF, 4, 64>(c, a, finest);
+        case 5: if constexpr (K <= 4) return launch_jacobikc_t<K, 4, 6, 1, true, PF, 2, 64>(c, a, finest);
+        default: return launch_jacobikc_t<K, 12, 2, 2, true, PF>(c, a, finest);
+    }
+}
+
 template <int K>
 int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest) {
-    if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false>(c, a, finest);      // (experiment: -1 / +1 neighbours through LDS)
-    switch (c->fuse_k_shape) {
-        case 1: return launch_jacobikc_t<K, 12, 4, 1, true>(c, a, finest);
-        case 2: return launch_jacobikc_t<K, 8, 3, 2, true>(c, a, finest);
-        default: return launch_jacobikc_t<K, 12, 2, 2, true>(c, a, finest);
+    // a second plane of x staged in registers ("fuse_k_pf" 2) fits the register budget with three sweeps only
+    if constexpr (K == 3) {
+        if (c->fuse_k_pf == 2) return launch_jacobikc_kp<K, 2>(c, a, finest);
     }
+    return launch_jacobikc_kp<K, 1>(c, a, finest);
 }
 
 // out = K Jacobi sweeps applied to x (3 <= K <= 5), whole levels
@@ -1207,6 +1226,7 @@ int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, 
     for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
     a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
     a.plo = a.phi = 0;
+    a.force_form = c->timing_force_form;
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     switch (K) {
         case 3: return launch_jacobikc_k<3>(c, a, finest);
@@ -2673,8 +2693,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         if (value < 0 || value > 5) return fail("fuse_k must be in 0..5 (below 3: pairs of sweeps only)");
         c->fuse_k = (int)value;
     } else if (k == "fuse_k_shape") {
-        if (value < 0 || value > 2) return fail("fuse_k_shape must be 0..2");
+        if (value < 0 || value > 5) return fail("fuse_k_shape must be 0..5");
         c->fuse_k_shape = (int)value;
+    } else if (k == "fuse_k_pf") {
+        if (value != 1 && value != 2) return fail("fuse_k_pf must be 1 or 2");
+        c->fuse_k_pf = (int)value;
     } else if (k == "fuse_k_dpp") {
         c->fuse_k_dpp = value != 0;
     } else if (k == "fuse_k_segments") {
@@ -3451,9 +3474,13 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             const J2Plan plan = jacobi2_plan(c, L, false, 0);
             return launch_jacobi2(c, L, plan, 0, 1, plan.nseg, L.v.rows, L.f.rows, L.v2.rows);
         }
-        if (k == "jacobik3" || k == "jacobik3!") {     // K = fuse_k sweeps per pass on a whole class-coded 3-D level
-            if (!sweepsk_ok(c, L, k == "jacobik3!")) return fail("level does not use the K-sweep pass");
-            return launch_jacobikc(c, L, std::min(c->fuse_k, 5), L.v.rows, L.f.rows, L.v2.rows);
+        if (k.rfind("jacobik3", 0) == 0) {     // K = fuse_k sweeps per pass on a whole class-coded 3-D level ("!": wherever it applies)
+            const bool forced = k.find(":form") != std::string::npos;
+            if (!sweepsk_ok(c, L, forced || k.find('!') != std::string::npos)) return fail("level does not use the K-sweep pass");
+            c->timing_force_form = forced ? k.back() - '0' : -1;
+            const int rc = launch_jacobikc(c, L, std::min(c->fuse_k, 5), L.v.rows, L.f.rows, L.v2.rows);
+            c->timing_force_form = -1;
+            return rc;
         }
         if (k == "jacobi_small") {           // all mu1 sweeps of a small level in one launch
             if (!small_level_ok(c, L) || c->mu1 < 2) return fail("level does not use the one-launch smoother");

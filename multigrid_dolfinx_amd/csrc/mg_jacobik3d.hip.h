@@ -57,33 +57,36 @@ struct JK3Args {
     int plo, phi;               // halo planes below / above whose rows exist on a neighbour (0: the level ends here)
     int ntx, nty, seglen;
     unsigned nitems, xcd_chunk;
+    int force_form;             // -1; timing experiments (mg_time_kernel only, results are wrong): every step in form 0 / 1 / 2
 };
 
-template <int K, int NW, int LPW, int M> constexpr size_t jk3_lds_bytes() {
-    return sizeof(double) * (256 * CLS_W + (size_t)K * (NW * LPW + 2) * (64 * M) + 2 * (64 * M + 2));
+// (TR: rows of the class table kept in LDS -- 256, or 64 for the shapes that run two workgroups per CU)
+template <int K, int NW, int LPW, int M, int TR> constexpr size_t jk3_lds_bytes() {
+    return sizeof(double) * (TR * CLS_W + (size_t)K * (NW * LPW + 2) * (64 * M) + 2 * (64 * M + 2));
 }
 
 // the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
 __device__ __forceinline__ double jk3_from_west(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xF, 0xF, false);     // wave_ror:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13C, 0xF, 0xF, true);      // wave_ror:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13C, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double jk3_from_east(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xF, 0xF, false);     // wave_rol:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xF, 0xF, true);      // wave_rol:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
-template <int K, int NW, int LPW, int M, bool DPP>
+template <int K, int NW, int LPW, int M, bool DPP, int PF, int TR>
 __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     constexpr int EX = 64 * M, EY = NW * LPW, NC = M * LPW, IMG = (EY + 2) * EX, CW = (NC + 3) / 4;
     constexpr int WI = EX - 2 * K, HY = EY - 2 * K + 2;       // cells per line / lines of a tile that get all K sweeps
     static_assert(NC * (K + 1) <= 64, "the fast-path flags live in one scalar register pair");
     static_assert(WI > 0 && HY > 0, "tile too small for K sweeps");
+    static_assert(PF == 1 || PF == 2, "planes of x in flight");
     extern __shared__ double j2_smem[];
     double* const sT = j2_smem;                               // 256 x 8   entries of the row classes, [7] = omega / diagonal
-    double* const sI = sT + 256 * CLS_W + (EX + 2);           // K x (EY+2) x EX   one plane of level t, origin (0,-1)
+    double* const sI = sT + TR * CLS_W + (EX + 2);           // K x (EY+2) x EX   one plane of level t, origin (0,-1)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
@@ -111,7 +114,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             }
             sT[i] = v;
         }
-        for (int i = threadIdx.x; i < K * IMG + 2 * (EX + 2); i += NW * WAVE) sT[256 * CLS_W + i] = 0.0;
+        for (int i = threadIdx.x; i < K * IMG + 2 * (EX + 2); i += NW * WAVE) sT[TR * CLS_W + i] = 0.0;
     }
     const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
     const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
@@ -172,16 +175,21 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
         asm volatile("" : "+v"(e8));
         return *(const __attribute__((address_space(1))) double*)(b + e8);
     };
+    // (the class byte arrives as the low byte of an unaligned 32-bit load and is masked where it is first used: a byte
+    //  load is masked by the compiler right behind the load -- which makes every wave wait for the loads it has just issued)
+    typedef unsigned int __attribute__((aligned(1))) u32_unaligned_t;
     auto ldc = [](gcptr_t b, unsigned e8) -> int {
         unsigned e = e8 >> 3;
         asm volatile("" : "+v"(e));
-        return *(const __attribute__((address_space(1))) unsigned char*)(b + e);
+        return (int)*(const __attribute__((address_space(1))) u32_unaligned_t*)(b + e);
     };
     const int pmin = -a.plo - 1, pmax = a.nz + a.phi;
 
     // registers per cell: K partial sums; f of the planes k .. k+K-1; x, f and the class of the plane that arrives
-    double acc[K][NC], fr[K][NC], X[NC], hy[M];
-    int C[NC];
+    double acc[K][NC], fr[K][NC];
+    // x, the classes and the y ring of x of the planes that arrive: PF sets, taken in turn by successive steps
+    double XA[NC], XB[PF == 2 ? NC : 1], hyA[M], hyB[PF == 2 ? M : 1];
+    int CA[NC], CB[PF == 2 ? NC : 1];
     unsigned cw[K + 1][CW];     // class bytes of the planes k .. k+K, four cells to a register
     unsigned long long fast = 0;        // wave-uniform; bit j*NC + c: all 64 cells c of plane k+j are of class cmain
     constexpr unsigned long long ALLFAST = (NC * (K + 1) == 64) ? ~0ull : ((1ull << (NC * (K + 1))) - 1ull);
@@ -189,30 +197,36 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int t = 0; t < K; ++t) acc[t][c] = fr[t][c] = 0.0;
-        X[c] = 0.0;
-        C[c] = 0;
+        XA[c] = 0.0;
+        CA[c] = 0;
     }
 #pragma unroll
     for (int j = 0; j <= K; ++j)
 #pragma unroll
         for (int q = 0; q < CW; ++q) cw[j][q] = 0u;
 #pragma unroll
-    for (int r = 0; r < M; ++r) hy[r] = 0.0;
+    for (int r = 0; r < M; ++r) hyA[r] = 0.0;
+    XB[0] = 0.0; hyB[0] = 0.0; CB[0] = 0;
 
-    // x and the classes of `plane`, f of the plane below it -- which a step needs one step later: it arrives in the
-    // slot of the ring that has just become free
-    auto load_plane = [&](const int plane) {
+    // Loads are issued in slices, slice i of n between the pieces of phase B: issued in one burst (14 per wave, all twelve
+    // waves at the same point of the step) they keep every wave at the vector-memory issue port in front of the barrier
+    // while nothing computes -- measured: the burst added its whole issue time to the step.
+    // Slice i: x and the classes of its cells of `plane` into a register set (the y ring with the last slice), f of the
+    // plane `fplane` into the slot of the ring that has just become free (a step needs it one step after x of that plane).
+    auto load_slice = [&](const int i, const int n, const int plane, const int fplane, double (&X)[NC], int (&C)[NC], double (&hy)[M])
+        __attribute__((always_inline)) {
         const int64_t o = (int64_t)min(max(plane, pmin), pmax) * a.P;
         const gcptr_t cb = sbase(clsb + o);
-        const gcptr_t fb = sbase(fb0 + (int64_t)min(max(plane - 1, pmin), pmax) * a.P);
         const gcptr_t xb = sbase(xb0 + o);
+        const gcptr_t fb = sbase(fb0 + (int64_t)min(max(fplane, pmin), pmax) * a.P);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if ((c * n) / NC != i) continue;
             X[c] = ldd(xb, eo[c]);
             C[c] = ldc(cb, eo[c]);
             fr[K - 1][c] = ldd(fb, eo[c]);
         }
-        if (wlo || whi) {
+        if (i == n - 1 && (wlo || whi)) {
 #pragma unroll
             for (int r = 0; r < M; ++r) hy[r] = ldd(xb, eor[r]);
         }
@@ -245,7 +259,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     // Straight-line form.  COL = false: every cell has the interior stencil, entries in scalar registers.  COL = true:
     // a cell's class depends on its lane only (tile columns along the x boundary, away from the other boundaries): the
     // entries of the lane's row come from the class table once per cell group and phase.
-    auto phase_a_fast = [&](auto col_tag) {
+    auto phase_a_fast = [&](auto col_tag, const double (&X)[NC]) __attribute__((always_inline)) {
         constexpr bool COL = decltype(col_tag)::value;
 #pragma unroll
         for (int r = 0; r < M; ++r) {
@@ -273,7 +287,9 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             }
         }
     };
-    auto phase_b_fast = [&](auto col_tag) {
+    // (phase B comes in K pieces, one per level, so that the loads can go out in COMMON code between them: a load issued
+    //  inside the branches of the three forms makes the compiler spill hundreds of registers)
+    auto phase_b_fast = [&](auto col_tag, const int t) __attribute__((always_inline)) {
         constexpr bool COL = decltype(col_tag)::value;
         double k1[M], k2[M], k3[M], k4[M], k5[M];
 #pragma unroll
@@ -285,52 +301,49 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
                 k1[r] = t01.y; k2[r] = t23.x; k3[r] = t23.y; k4[r] = t45.x; k5[r] = t45.y;
             }
         }
+        const double* const img = image(t - 1);
+        double v[LPW][M], ys[M], yn[M];
 #pragma unroll
-        for (int t = 1; t <= K; ++t) {
-            const double* const img = image(t - 1);
-            double v[LPW][M], ys[M], yn[M];
+        for (int r = 0; r < M; ++r) {
+            ys[r] = img[-EX + 64 * r];
 #pragma unroll
-            for (int r = 0; r < M; ++r) {
-                ys[r] = img[-EX + 64 * r];
+            for (int l = 0; l < LPW; ++l) v[l][r] = img[l * EX + 64 * r];
+            yn[r] = img[LPW * EX + 64 * r];
+        }
 #pragma unroll
-                for (int l = 0; l < LPW; ++l) v[l][r] = img[l * EX + 64 * r];
-                yn[r] = img[LPW * EX + 64 * r];
-            }
+        for (int l = 0; l < LPW; ++l) {
+            double yw[M], ye[M];
+            if constexpr (DPP) {
+                double fw[M], fe[M];
 #pragma unroll
-            for (int l = 0; l < LPW; ++l) {
-                double yw[M], ye[M];
-                if constexpr (DPP) {
-                    double fw[M], fe[M];
-#pragma unroll
-                    for (int r = 0; r < M; ++r) { fw[r] = jk3_from_west(v[l][r]); fe[r] = jk3_from_east(v[l][r]); }
-#pragma unroll
-                    for (int r = 0; r < M; ++r) {
-                        yw[r] = (r > 0 && lane == 0) ? fw[r > 0 ? r - 1 : 0] : fw[r];
-                        ye[r] = (r + 1 < M && lane == 63) ? fe[r + 1 < M ? r + 1 : r] : fe[r];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < M; ++r) {
-                        yw[r] = img[l * EX + 64 * r - 1];
-                        ye[r] = img[l * EX + 64 * r + 1];
-                    }
-                }
+                for (int r = 0; r < M; ++r) { fw[r] = jk3_from_west(v[l][r]); fe[r] = jk3_from_east(v[l][r]); }
 #pragma unroll
                 for (int r = 0; r < M; ++r) {
-                    const int c = l * M + r;
-                    double s = acc[t - 1][c];
-                    s = fma(k1[r], l > 0 ? v[l > 0 ? l - 1 : 0][r] : ys[r], s);
-                    s = fma(k2[r], yw[r], s);
-                    s = fma(k3[r], v[l][r], s);
-                    s = fma(k4[r], ye[r], s);
-                    s = fma(k5[r], l + 1 < LPW ? v[l + 1 < LPW ? l + 1 : l][r] : yn[r], s);
-                    acc[t - 1][c] = s;
+                    yw[r] = (r > 0 && lane == 0) ? fw[r > 0 ? r - 1 : 0] : fw[r];
+                    ye[r] = (r + 1 < M && lane == 63) ? fe[r + 1 < M ? r + 1 : r] : fe[r];
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < M; ++r) {
+                    yw[r] = img[l * EX + 64 * r - 1];
+                    ye[r] = img[l * EX + 64 * r + 1];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                const int c = l * M + r;
+                double s = acc[t - 1][c];
+                s = fma(k1[r], l > 0 ? v[l > 0 ? l - 1 : 0][r] : ys[r], s);
+                s = fma(k2[r], yw[r], s);
+                s = fma(k3[r], v[l][r], s);
+                s = fma(k4[r], ye[r], s);
+                s = fma(k5[r], l + 1 < LPW ? v[l + 1 < LPW ? l + 1 : l][r] : yn[r], s);
+                acc[t - 1][c] = s;
             }
         }
     };
     // General form: every cell's entries from the class table, rows outside the level masked to zero.
-    auto phase_a_general = [&]() {
+    auto phase_a_general = [&](const double (&X)[NC]) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int iw = lwof(c);
@@ -356,32 +369,31 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             if (k_store && (inT >> c & 1u)) store(c, nw);
         }
     };
-    auto phase_b_general = [&]() {
+    auto phase_b_general = [&](const int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int iw = lwof(c);
-#pragma unroll
-            for (int t = 1; t <= K; ++t) {
-                const double* const img = image(t - 1);
-                const double ys = img[iw - EX], yw = img[iw - 1], yd = img[iw], ye = img[iw + 1], yn = img[iw + EX];
-                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_now(K - t, c));
-                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
-                double s = acc[t - 1][c];
-                s = fma(t01.y, ys, s);
-                s = fma(t23.x, yw, s);
-                s = fma(t23.y, yd, s);
-                s = fma(t45.x, ye, s);
-                s = fma(t45.y, yn, s);
-                acc[t - 1][c] = s;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const double* const img = image(t - 1);
+            const double ys = img[iw - EX], yw = img[iw - 1], yd = img[iw], ye = img[iw + 1], yn = img[iw + EX];
+            const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_now(K - t, c));
+            const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
+            double s = acc[t - 1][c];
+            s = fma(t01.y, ys, s);
+            s = fma(t23.x, yw, s);
+            s = fma(t23.y, yd, s);
+            s = fma(t45.x, ye, s);
+            s = fma(t45.y, yn, s);
+            acc[t - 1][c] = s;
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    load_plane(z0 - K);
-    __syncthreads();
-
-    for (int k = z0 - 2 * K; k < z1; ++k) {
+    // One step: `X, C, hy` hold plane k+K (arrived).  PF = 1: when phase A has consumed them, the loads of plane k+K+1 go out
+    // into the same registers and are in flight through phase B.  PF = 2: a second set `XN, CN, hyN` holds plane k+K+1, in
+    // flight since the step before; when phase A has consumed the first set it takes the second one over (a whole step
+    // after those loads went out) and the loads of plane k+K+2 go out into the second set: a plane is in flight at all times.
+    auto step = [&](const int k, double (&X)[NC], int (&C)[NC], double (&hy)[M], double (&XN)[PF == 2 ? NC : 1],
+                    int (&CN)[PF == 2 ? NC : 1], double (&hyN)[PF == 2 ? M : 1]) __attribute__((always_inline)) {
         k_plane = k; k_store = k >= z0;
         {
             const unsigned long long u = (unsigned long long)(a.out - bias + (int64_t)k * a.P);
@@ -390,6 +402,14 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             k_out = (__attribute__((address_space(1))) char*)(((unsigned long long)hi << 32) | lo);
         }
         // ---- the plane k+K has arrived: its classes join the ring ----
+        // (the loaded values are first touched HERE: left alone the compiler masks the class bytes right behind their
+        //  loads, a step early, and every wave then waits for its loads before the barrier instead of computing)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            asm volatile("" : "+v"(C[c]));
+            asm volatile("" : "+v"(X[c]));
+            C[c] &= 255;
+        }
         {
             unsigned m = 0;
 #pragma unroll
@@ -416,16 +436,17 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
                 if (__builtin_amdgcn_readfirstlane((int)(__ballot(!same) == 0ull))) form = 1;
             }
         }
+        if (a.force_form >= 0) form = a.force_form;
         // ---- phase A: finish plane k+K-t of level t, t = 1 .. K; start the plane above it ----
-        if (form == 0) phase_a_fast(std::false_type{});
-        else if (form == 1) phase_a_fast(std::true_type{});
-        else phase_a_general();
+        if (form == 0) phase_a_fast(std::false_type{}, X);
+        else if (form == 1) phase_a_fast(std::true_type{}, X);
+        else phase_a_general(X);
         if (wlo || whi) {
             double* const ring = image(0) + (wlo ? -EX : LPW * EX);
 #pragma unroll
             for (int r = 0; r < M; ++r) ring[64 * r] = hy[r];
         }
-        // ---- the rings move on; the loads of the next plane go out ----
+        // ---- the rings move on; the next loads go out ----
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -437,25 +458,57 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
 #pragma unroll
             for (int q = 0; q < CW; ++q) cw[j][q] = cw[j + 1][q];
         fast >>= NC;
-        load_plane(k + K + 1);
         __syncthreads();
-        // ---- phase B: the in-plane terms of the planes started above (ring index K - t of the moved ring) ----
-        if (form == 0) phase_b_fast(std::false_type{});
-        else if (form == 1) phase_b_fast(std::true_type{});
-        else phase_b_general();
+        // ---- phase B: the in-plane terms of the planes started above (ring index K - t of the moved ring); the next
+        //      loads go out between its pieces ----
+        if constexpr (PF == 2) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                X[c] = XN[c]; C[c] = CN[c];
+                asm volatile("" : "+v"(X[c]));
+                asm volatile("" : "+v"(C[c]));
+            }
+            if (wlo || whi) {
+#pragma unroll
+                for (int r = 0; r < M; ++r) { hy[r] = hyN[r]; asm volatile("" : "+v"(hy[r])); }
+            }
+        }
+        auto issue = [&](const int i, const int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PF == 2) load_slice(i, n, k + K + 2, k + K, XN, CN, hyN);
+            else load_slice(i, n, k + K + 1, k + K, X, C, hy);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int t = 1; t <= K; ++t) {
+            if (form == 0) phase_b_fast(std::false_type{}, t);
+            else if (form == 1) phase_b_fast(std::true_type{}, t);
+            else phase_b_general(t);
+            issue(t - 1, K);
+        }
         __syncthreads();
-    }
+    };
+
+    load_slice(0, 1, z0 - K, z0 - K - 1, XA, CA, hyA);
+    if constexpr (PF == 2) load_slice(0, 1, z0 - K + 1, z0 - K - 1, XB, CB, hyB);      // (f of the same plane once more)
+    __syncthreads();
+
+    for (int k = z0 - 2 * K; k < z1; ++k) step(k, XA, CA, hyA, XB, CB, hyB);
 }
 
-template <int K, int NW, int LPW, int M, bool DPP>
-__global__ __launch_bounds__(NW * WAVE) void sdia_jacobikc(JK3Args a) {
-    jk3_body<K, NW, LPW, M, DPP>(a);
+// WPE: waves per SIMD the register budget is set for (12-wave workgroups: 3, one per CU; 6- and 8-wave workgroups: 3 / 4,
+// two per CU, so that one workgroup's waves run while the other's wait at a barrier)
+template <int K, int NW, int LPW, int M, bool DPP, int PF, int WPE, int TR>
+__global__ __attribute__((amdgpu_flat_work_group_size(NW * WAVE, NW * WAVE), amdgpu_waves_per_eu(WPE, WPE)))
+void sdia_jacobikc(JK3Args a) {
+    jk3_body<K, NW, LPW, M, DPP, PF, TR>(a);
 }
 
 // (its own symbol for the finest level, so that profiler summaries list the dominant launches apart)
-template <int K, int NW, int LPW, int M, bool DPP>
-__global__ __launch_bounds__(NW * WAVE) void sdia_jacobikc_finest(JK3Args a) {
-    jk3_body<K, NW, LPW, M, DPP>(a);
+template <int K, int NW, int LPW, int M, bool DPP, int PF, int WPE, int TR>
+__global__ __attribute__((amdgpu_flat_work_group_size(NW * WAVE, NW * WAVE), amdgpu_waves_per_eu(WPE, WPE)))
+void sdia_jacobikc_finest(JK3Args a) {
+    jk3_body<K, NW, LPW, M, DPP, PF, TR>(a);
 }
 
 }  // namespace mgk

@@ -66,6 +66,12 @@ def rank_main(rank):
         start.abort()
 
 
+if os.environ.get("MG_DUMP_MAPS"):
+    # which library an address of a native stack trace belongs to (the profiler's traces print raw addresses): the
+    # executable mappings of this process, written before the ranks start
+    with open("/proc/self/maps") as src, open(os.environ["MG_DUMP_MAPS"], "w") as dst:
+        dst.writelines(line for line in src if " r-xp " in line or "stack" in line)
+
 threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
 for t in threads:
     t.start()

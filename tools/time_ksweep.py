@@ -20,13 +20,20 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=50, mu2=50) as h:
     for spec in specs:
         for kv in spec.split(","):
             key, val = kv.split("=")
-            h.set_tuning(key, int(val))
+            if key not in ("form", "skip"):
+                h.set_tuning(key, int(val))
         k = next(int(kv.split("=")[1]) for kv in spec.split(",") if kv.startswith("fuse_k="))
-        ms = h.time_kernel("jacobik3!", hi, reps)
+        form = next((kv.split("=")[1] for kv in spec.split(",") if kv.startswith("form=")), None)
+        skip = next((kv.split("=")[1] for kv in spec.split(",") if kv.startswith("skip=")), None)
+        name = "jacobik3" + (":skip" + skip if skip else "") + (":form" + form if form else "!")
+        ms = h.time_kernel(name, hi, reps)
         print(f"{spec:44s} {ms:8.3f} ms = {ms / k:6.3f} ms per sweep, {25 * n / ms / 1e6:7.1f} GB/s on 25 B/row", flush=True)
-        for key in ("fuse_k_shape", "fuse_k_segments"):
-            h.set_tuning(key, 0)
+        h.set_tuning("fuse_k_shape", 1)
+        h.set_tuning("fuse_k_segments", 0)
         h.set_tuning("fuse_k_dpp", 1)
+        h.set_tuning("fuse_k_pf", 1)
+    if os.environ.get("MG_SKIP_CYCLES"):
+        sys.exit(0)
     for k in (0, 3, 4, 5):
         h.set_tuning("fuse_k", k)
         h.zero_vector(hi, "v")
