@@ -215,6 +215,17 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_min_rows"      ... only on levels with at least this many owned rows (16777216)
  *     "fuse_segments"      plane segments per tile of that pass, 0 = chosen by the cost model (0)
  *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
+ *     "fuse_k"             Jacobi sweeps per pass of the K-sweep march (mg_jacobik3d.hip.h) on whole seven-point levels with
+ *                          row classes: a smoother call of nw sweeps (multigrid.py:223-228) runs as passes of 3 .. "fuse_k"
+ *                          sweeps and at most one pair; 0 .. 2 = pairs only (4); bit-identical to single sweeps
+ *     "fuse_k_shape"       tile of that march: 0 = 128 x 24 cells (12 waves x 2 grid lines), 1 = 64 x 48 (12 waves x 4 lines),
+ *                          2 = 128 x 24 (8 waves x 3 lines), 3 / 4 / 5 = 64 x 24 by 6 / 8 / 4 waves with two workgroups per CU
+ *                          (levels of at most 64 row classes) (1: measured best)
+ *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
+ *     "fuse_k_pf"          register sets for the planes of x that arrive: 2 = a second set keeps x staged one step longer
+ *                          (three sweeps per pass only) (1: measured no slower)
+ *     "fuse_k_dpp"         0 = the -1 / +1 neighbours of that march come through LDS instead of the neighbouring lanes'
+ *                          registers (experiment, tile 0 only: measured 1.4 x slower) (1)
  *     "fuse_classes"       that pass reads one class byte per row instead of the 32-byte row where the level has
  *                          row classes (1); bit-identical either way
  *     "fuse_plain"         that pass on levels WITHOUT row classes: 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's (2);
