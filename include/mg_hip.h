@@ -195,6 +195,11 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          per entry -- below the round-off of the assembly itself for small k -- so results agree with the
  *                          exact-storage ones to ~k * 1e-16 relative, not bit for bit.  (0: everything bit for bit)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
+ *     "halo_depth"         halo planes every vector of a slab has ROOM for, >= "halo_planes" (0 .. 5; 0: just those).  With K
+ *                          planes of room the K-sweep march ("fuse_k") runs on slabs too: K planes of the iterate travel once per
+ *                          K sweeps and the slab relaxes its neighbours' K - 1 planes next to it itself -- one grouped exchange
+ *                          and two launches per K sweeps instead of a boundary chain per pair; bit-identical to the single
+ *                          handle.  Every rank alike, before mg_set_comm / level set-up.  (0)
  *   any time:
  *     "xcd_chunk"          consecutive tiles per XCD in the chunked block -> tile map (8)
  *     "strip_slices"       slices per XCD strip, 0 = chunked map only (64)
@@ -222,6 +227,7 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          2 = 128 x 24 (8 waves x 3 lines), 3 / 4 / 5 = 64 x 24 by 6 / 8 / 4 waves with two workgroups per CU
  *                          (levels of at most 64 row classes) (1: measured best)
  *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
+ *     "fuse_k_slab_min_rows"  ... on slabs (below): levels whose smallest slab has at least this many rows (1048576)
  *     "fuse_k_pf"          register sets for the planes of x that arrive: 2 = a second set keeps x staged one step longer
  *                          (three sweeps per pass only) (1: measured no slower)
  *     "fuse_k_dpp"         0 = the -1 / +1 neighbours of that march come through LDS instead of the neighbouring lanes'

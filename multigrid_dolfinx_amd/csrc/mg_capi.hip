@@ -127,6 +127,8 @@ struct Level {
     Grid g{};
     int64_t n_global = 0, row0 = 0, nloc = 0, xlen = 0, halo_lo = 0, halo_hi = 0;
     bool replicated = true;      // false: this rank holds one slab and exchanges halos
+    int hd = 0;                  // halo planes each vector of this level has room for (slabs)
+    int cls_halo = 0;            // row classes of the neighbours' planes next to this slab: 0 not built yet, 1 in place, -1 unavailable
     bool flat = false;           // no grid structure (stand-alone smoother on any matrix)
     int W = 0, R = 1;
     int64_t nslices = 0;
@@ -199,6 +201,8 @@ struct mg_context {
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     int overlap = 1;
     int halo_planes = 1;                    // grid planes exchanged with each slab neighbour (2: stencils that reach two planes, P2)
+    int halo_depth = 0;                     // halo planes ALLOCATED per vector (>= halo_planes; 0: just those): the K-sweep march on slabs
+                                            // exchanges K planes once per K sweeps (mg_jacobik3d.hip.h)
     int64_t overlap_min_rows = (int64_t)1 << 22;
     std::vector<Level> L;
     int mu1 = 50, mu2 = 50;
@@ -260,6 +264,7 @@ struct mg_context {
     int fuse_k_segments = 0;        // ... plane segments per tile (0: chosen from the item count)
     int timing_force_form = -1;     // mg_time_kernel("jacobik3:formN"): every step of the K-sweep pass in one form (wrong results; how fast
                                     // each form is by itself)
+    int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
@@ -419,8 +424,10 @@ int setup_geometry(mg_context* c, Level& L, int level, int N, int64_t flat_rows 
         g.k0 = L.splits[cm.rank];
         g.nk = L.splits[cm.rank + 1] - g.k0;
         if ((N0 / cm.world) << level < c->halo_planes) return fail("a slab is thinner than the halo");
-        L.halo_lo = cm.rank > 0 ? c->halo_planes * g.plane : 0;
-        L.halo_hi = cm.rank + 1 < cm.world ? c->halo_planes * g.plane : 0;
+        // room for "halo_depth" planes where the thinnest slab of the level has as many (every rank alike)
+        L.hd = std::max(c->halo_planes, std::min(c->halo_depth, (N0 / cm.world) << level));
+        L.halo_lo = cm.rank > 0 ? L.hd * g.plane : 0;
+        L.halo_hi = cm.rank + 1 < cm.world ? L.hd * g.plane : 0;
     } else {
         g.k0 = 0;
         g.nk = g.nz;
@@ -469,6 +476,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.cls, (size_t)L.cls_rows);
     dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
+    L.cls_halo = 0;
     dev_free(c, L.scls, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.s_off, (size_t)256 * L.W);
     dev_free(c, L.s_val, (size_t)256 * L.W);
@@ -681,7 +689,8 @@ int launch_lat_march(mg_context* c, const Level& L, int mode, const double* x_ro
     a.cls = L.scls; a.s_pack = L.s_pack; a.s_val = L.s_val; a.s_cnt = L.s_cnt;
     a.W = L.W; a.WP = (L.W + 3) / 4 * 4 + 4; a.ntop = L.lm_ntop;
     for (int t = 0; t < LM_K; ++t) a.top[t] = L.lm_top[t];
-    a.nloc = L.nloc; a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.P = L.g.plane;
+    a.nloc = L.nloc; a.P = L.g.plane;
+    a.xlo = -(L.halo_lo ? (int64_t)c->halo_planes * L.g.plane : 0); a.xhi = L.nloc + (L.halo_hi ? (int64_t)c->halo_planes * L.g.plane : 0);
     a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.kg0 = (int)(L.row0 / L.g.plane);
     a.color = color; a.omega = c->omega;
     // ("lattice_tile" 2: the wide tile moves 23 % fewer bytes but its one 512-thread workgroup per CU is slower than two of
@@ -813,44 +822,49 @@ int ensure_host_stage(mg_context* c, size_t elems) {
     return 0;
 }
 
-// Fill the halo planes of `v` from the neighbouring slabs (the first `halo_planes` owned planes go down, the last ones
-// go up).
-int exchange_halo(mg_context* c, const Level& L, DVector& v, hipStream_t stream = nullptr) {
-    if (!stream) stream = c->stream;
+// `count` doubles to and from each slab neighbour (device buffers; a rank without that neighbour passes nothing)
+int exchange_raw(mg_context* c, const double* send_lo, const double* send_hi, double* recv_lo, double* recv_hi, size_t count,
+                 hipStream_t stream) {
     Comm& cm = c->comm;
-    if (L.replicated || !cm.active()) return 0;
-    const size_t plane = (size_t)c->halo_planes * (size_t)L.g.plane;       // elements per message
     const bool lo = cm.rank > 0, hi = cm.rank + 1 < cm.world;
-    double* send_lo = v.rows;
-    double* send_hi = v.rows + L.nloc - plane;
-    double* recv_lo = v.base;
-    double* recv_hi = v.rows + L.nloc;
     if (cm.nccl) {
         NCCL_TRY(g_rccl.GroupStart());
         if (lo) {
-            NCCL_TRY(g_rccl.Send(send_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, stream));
-            NCCL_TRY(g_rccl.Recv(recv_lo, plane, ncclDouble, cm.rank - 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Send(send_lo, count, ncclDouble, cm.rank - 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Recv(recv_lo, count, ncclDouble, cm.rank - 1, cm.nccl, stream));
         }
         if (hi) {
-            NCCL_TRY(g_rccl.Send(send_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, stream));
-            NCCL_TRY(g_rccl.Recv(recv_hi, plane, ncclDouble, cm.rank + 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Send(send_hi, count, ncclDouble, cm.rank + 1, cm.nccl, stream));
+            NCCL_TRY(g_rccl.Recv(recv_hi, count, ncclDouble, cm.rank + 1, cm.nccl, stream));
         }
         NCCL_TRY(g_rccl.GroupEnd());
         return 0;
     }
     if (!cm.ex) return fail("no transport configured");
-    MG_TRY(ensure_host_stage(c, 4 * plane));
+    MG_TRY(ensure_host_stage(c, 4 * count));
     double* h = cm.h_stage;
-    if (lo) HIP_TRY(hipMemcpyAsync(h, send_lo, plane * 8, hipMemcpyDeviceToHost, stream));
-    if (hi) HIP_TRY(hipMemcpyAsync(h + plane, send_hi, plane * 8, hipMemcpyDeviceToHost, stream));
+    if (lo) HIP_TRY(hipMemcpyAsync(h, send_lo, count * 8, hipMemcpyDeviceToHost, stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(h + count, send_hi, count * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (cm.ex(cm.user, lo ? h : nullptr, hi ? h + plane : nullptr, lo ? h + 2 * plane : nullptr,
-              hi ? h + 3 * plane : nullptr, (int64_t)plane) != 0)
+    if (cm.ex(cm.user, lo ? h : nullptr, hi ? h + count : nullptr, lo ? h + 2 * count : nullptr,
+              hi ? h + 3 * count : nullptr, (int64_t)count) != 0)
         return fail("exchange callback failed");
-    if (lo) HIP_TRY(hipMemcpyAsync(recv_lo, h + 2 * plane, plane * 8, hipMemcpyHostToDevice, stream));
-    if (hi) HIP_TRY(hipMemcpyAsync(recv_hi, h + 3 * plane, plane * 8, hipMemcpyHostToDevice, stream));
+    if (lo) HIP_TRY(hipMemcpyAsync(recv_lo, h + 2 * count, count * 8, hipMemcpyHostToDevice, stream));
+    if (hi) HIP_TRY(hipMemcpyAsync(recv_hi, h + 3 * count, count * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
+}
+
+// Fill the `planes` halo planes of `v` NEXT TO its owned rows from the neighbouring slabs (the first owned planes go down,
+// the last ones go up); planes < 0: as many as one application of the level's rows reaches ("halo_planes").
+int exchange_halo(mg_context* c, const Level& L, DVector& v, hipStream_t stream = nullptr, int planes = -1) {
+    if (!stream) stream = c->stream;
+    Comm& cm = c->comm;
+    if (L.replicated || !cm.active()) return 0;
+    if (planes < 0) planes = c->halo_planes;
+    if (planes > L.hd) return fail("the vectors of this level have no room for that many halo planes");
+    const size_t count = (size_t)planes * (size_t)L.g.plane;       // elements per message
+    return exchange_raw(c, v.rows, v.rows + L.nloc - count, v.rows - count, v.rows + L.nloc, count, stream);
 }
 
 // In-place sum of `count` device doubles over all ranks.
@@ -1113,7 +1127,8 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     a.nloc = L.nloc; a.mlead = L.mlead; a.P = L.g.plane;
     a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
     a.zero = L.f.raw;
-    a.xlo = -L.halo_lo; a.xhi = L.nloc + L.halo_hi; a.slo = -L.halo_lo;
+    a.xlo = -(L.halo_lo ? (int64_t)c->halo_planes * L.g.plane : 0); a.xhi = L.nloc + (L.halo_hi ? (int64_t)c->halo_planes * L.g.plane : 0);
+    a.slo = a.xlo;
     a.st_lo = st_lo; a.st_hi = st_hi; a.v1out = v1_rows;
     a.k1_lo = st_lo + L.g.plane + L.g.nx + 2; a.k1_hi = st_hi - L.g.plane - L.g.nx - 2;
     a.ntx = plan.ntx; a.nty = plan.nty; a.nseg = plan.nseg; a.zb = plan.zb; a.seglen = plan.seglen;
@@ -1153,33 +1168,135 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     return launch_jacobi2_t<4, 8, 2>(c, a, n, finest);
 }
 
-// K sweeps per pass (mg_jacobik3d.hip.h): whole seven-point levels with row classes that use the two-sweep pass.
+// ---- row classes of the neighbours' planes (slabs, K-sweep march) --------------------------------------------------
+__global__ void bytes_to_doubles(const unsigned char* __restrict__ in, double* __restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = (double)in[t];
+}
+__global__ void doubles_to_classes(const double* __restrict__ in, const int* __restrict__ map, unsigned char* __restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = (unsigned char)map[(int)in[t] & 255];
+}
+
+// The march relaxes the K - 1 planes of either neighbour next to this slab along with its own (mg_jacobik3d.hip.h), so
+// it needs their rows: as class bytes in front of / behind the slab's own in `cls`, in THIS rank's class numbering.
+// Every rank builds its dictionary by itself, so the neighbours send their class bytes together with their tables, and
+// a class is translated by looking its row up in the own table (bit for bit; an unknown row is appended).  Collective:
+// every rank of a distributed level calls it at the same point; if one of them cannot translate (more than 255 classes),
+// all of them leave the march alone on this level.
+int ensure_class_halos(mg_context* c, Level& L) {
+    if (L.cls_halo != 0) return 0;
+    L.cls_halo = -1;
+    Comm& cm = c->comm;
+    const bool lo = cm.rank > 0, hi = cm.rank + 1 < cm.world;
+    const size_t n = (size_t)L.hd * (size_t)L.g.plane, nt = 256 * CLS_W + 8;
+    struct Buf {
+        double* p = nullptr;
+        ~Buf() { if (p) (void)hipFree(p); }
+    } send, recv, tsend, trecv, dmap;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&send.p), 2 * n * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&recv.p), 2 * n * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tsend.p), nt * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&trecv.p), 2 * nt * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dmap.p), 2 * 256 * sizeof(int)));
+    const unsigned nb = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+    int ok = L.cls != nullptr && L.ncls > 0 && L.sdia && L.wu == 4 && L.up[1] == 1 && L.up[2] == L.g.nx && (int64_t)L.up[3] == L.g.plane ? 1 : 0;
+    std::vector<double> mine(nt, 0.0), theirs(2 * nt, 0.0);
+    if (ok) {
+        hipLaunchKernelGGL(bytes_to_doubles, dim3(nb), dim3(256), 0, c->stream, L.cls + L.cls_lead, send.p, (int64_t)n);
+        hipLaunchKernelGGL(bytes_to_doubles, dim3(nb), dim3(256), 0, c->stream, L.cls + L.cls_lead + L.nloc - (int64_t)n, send.p + n, (int64_t)n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(mine.data() + 8, L.ctab, 256 * CLS_W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        mine[0] = (double)L.ncls;
+    }
+    // (a rank without classes still takes part in the exchanges: ncls = 0 tells the neighbours)
+    HIP_TRY(hipMemcpyAsync(tsend.p, mine.data(), nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!ok) HIP_TRY(hipMemsetAsync(send.p, 0, 2 * n * sizeof(double), c->stream));
+    MG_TRY(exchange_raw(c, send.p, send.p + n, recv.p, recv.p + n, n, c->stream));
+    MG_TRY(exchange_raw(c, tsend.p, tsend.p, trecv.p, trecv.p + nt, nt, c->stream));
+    HIP_TRY(hipMemcpyAsync(theirs.data(), trecv.p, 2 * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int> map(512, 0);
+    int ncls = L.ncls;
+    bool grown = false;
+    for (int side = 0; side < 2 && ok; ++side) {
+        if (!(side == 0 ? lo : hi)) continue;
+        const double* t = theirs.data() + (size_t)side * nt;
+        const int n_theirs = (int)t[0];
+        if (n_theirs <= 0 || n_theirs > 256) { ok = 0; break; }
+        for (int j = 0; j < n_theirs && ok; ++j) {
+            const double* row = t + 8 + (size_t)j * CLS_W;
+            int found = -1;
+            for (int i = 0; i < ncls && found < 0; ++i)
+                if (std::memcmp(mine.data() + 8 + (size_t)i * CLS_W, row, 7 * sizeof(double)) == 0) found = i;
+            if (found < 0) {
+                if (ncls >= 256) { ok = 0; break; }
+                std::memcpy(mine.data() + 8 + (size_t)ncls * CLS_W, row, 7 * sizeof(double));
+                mine[8 + (size_t)ncls * CLS_W + 7] = 0.0;
+                found = ncls++;
+                grown = true;
+            }
+            map[(size_t)side * 256 + j] = found;
+        }
+    }
+    // every rank or none
+    double flag = ok ? 0.0 : 1.0;
+    HIP_TRY(hipMemcpyAsync(c->scalars + 7, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    MG_TRY(allreduce_sum(c, c->scalars + 7, 1));
+    HIP_TRY(hipMemcpyAsync(&flag, c->scalars + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag != 0.0) return 0;
+    if (grown) {
+        HIP_TRY(hipMemcpyAsync(L.ctab, mine.data() + 8, 256 * CLS_W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        L.ncls = ncls;
+    }
+    HIP_TRY(hipMemcpyAsync(dmap.p, map.data(), 512 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int* dm = reinterpret_cast<const int*>(dmap.p);
+    if (lo) hipLaunchKernelGGL(doubles_to_classes, dim3(nb), dim3(256), 0, c->stream, recv.p, dm, L.cls + L.cls_lead - (int64_t)n, (int64_t)n);
+    if (hi) hipLaunchKernelGGL(doubles_to_classes, dim3(nb), dim3(256), 0, c->stream, recv.p + n, dm + 256, L.cls + L.cls_lead + L.nloc, (int64_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    L.cls_halo = 1;
+    return 0;
+}
+
+// K sweeps per pass (mg_jacobik3d.hip.h): seven-point levels with row classes that use the two-sweep pass -- whole levels,
+// and slabs whose vectors have room for K halo planes ("halo_depth").
 bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
-    if (c->fuse_k < 3 || !L.cls || !c->fuse_classes || !L.replicated) return false;
+    if (c->fuse_k < 3 || !L.cls || !c->fuse_classes) return false;
+    if (!L.replicated && c->comm.active() && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
     return fused_sweeps_ok(c, L, ignore_size) && L.g.nk >= 8;
 }
 
+// plane ranges of one launch of the march: [za0, za1) and then [zb0, zb1)
+struct JK3Range { int za0, za1, zb0, zb1; };
+
 template <int K, int NW, int LPW, int M, bool DPP, int PF = 1, int WPE = (NW == 12 ? 3 : 2), int TR = 256>
-int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
+int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest, const JK3Range& zr, int seglen) {
     constexpr int EX = 64 * M, EY = NW * LPW, WI = EX - 2 * K, HY = EY - 2 * K + 2;
     a.ntx = (a.nx + WI - 1) / WI;
     a.nty = (a.ny + HY - 1) / HY;
     const int64_t ntile = (int64_t)a.ntx * a.nty;
-    // plane segments: rounds of one resident workgroup per CU, each item paying 2K steps of warm-up (which do about
-    // two thirds of a step's work)
     constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M, TR>();
     static_assert(lds <= 160 * 1024, "one CU's LDS");
-    // (resident workgroups per CU: by LDS and by waves per SIMD)
-    const int64_t cus = std::max(1, c->prop.multiProcessorCount) * (int64_t)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(4 * WPE / NW)));
-    int best = 1;
-    double best_cost = 1e300;
-    for (int n = 1; n <= std::max(1, a.nz / 16); ++n) {
-        const double cost = (double)((ntile * n + cus - 1) / cus) * ((a.nz + n - 1) / n + 1.4 * K);
-        if (cost < best_cost) { best_cost = cost; best = n; }
+    a.za0 = zr.za0; a.za1 = zr.za1; a.zb0 = zr.zb0; a.zb1 = zr.zb1;
+    const int planes = std::max(0, zr.za1 - zr.za0) + std::max(0, zr.zb1 - zr.zb0);
+    if (planes <= 0) return 0;
+    if (seglen <= 0) {
+        // plane segments: rounds of the resident workgroups (by LDS and by waves per SIMD), each item paying 2K steps of
+        // warm-up (which do about two thirds of a step's work)
+        const int64_t cus = std::max(1, c->prop.multiProcessorCount) * (int64_t)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(4 * WPE / NW)));
+        int best = 1;
+        double best_cost = 1e300;
+        for (int n = 1; n <= std::max(1, planes / 8); ++n) {
+            const double cost = (double)((ntile * n + cus - 1) / cus) * ((planes + n - 1) / n + 1.4 * K);
+            if (cost < best_cost) { best_cost = cost; best = n; }
+        }
+        if (c->fuse_k_segments > 0) best = std::min(c->fuse_k_segments, planes);
+        seglen = (planes + best - 1) / best;
     }
-    if (c->fuse_k_segments > 0) best = std::min(c->fuse_k_segments, a.nz);
-    a.seglen = (a.nz + best - 1) / best;
-    const int nseg = (a.nz + a.seglen - 1) / a.seglen;
+    a.seglen = seglen;
+    const int nseg = (std::max(0, zr.za1 - zr.za0) + seglen - 1) / seglen + (std::max(0, zr.zb1 - zr.zb0) + seglen - 1) / seglen;
     const int64_t items = ntile * nseg;
     if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
     a.nitems = (unsigned)items;
@@ -1195,44 +1312,53 @@ int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest) {
 }
 
 template <int K, int PF>
-int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest) {
-    if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false, PF>(c, a, finest);     // (experiment: -1 / +1 neighbours through LDS)
+int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest, const JK3Range& zr, int seglen) {
+    if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false, PF>(c, a, finest, zr, seglen);     // (experiment: -1 / +1 neighbours through LDS)
     // shapes 3..5: 64 x 24 tiles, two workgroups per CU (class table of 64 rows); levels with more classes take shape 1
     const int shape = c->fuse_k_shape >= 3 && a.ncls > 64 ? 1 : c->fuse_k_shape;
     switch (shape) {
-        case 1: return launch_jacobikc_t<K, 12, 4, 1, true, PF>(c, a, finest);
-        case 2: return launch_jacobikc_t<K, 8, 3, 2, true, PF>(c, a, finest);
-        case 3: return launch_jacobikc_t<K, 6, 4, 1, true, PF, 3, 64>(c, a, finest);
-        case 4: return launch_jacobikc_t<K, 8, 3, 1, true, PF, 4, 64>(c, a, finest);
-        case 5: if constexpr (K <= 4) return launch_jacobikc_t<K, 4, 6, 1, true, PF, 2, 64>(c, a, finest);
-        default: return launch_jacobikc_t<K, 12, 2, 2, true, PF>(c, a, finest);
+        case 1: return launch_jacobikc_t<K, 12, 4, 1, true, PF>(c, a, finest, zr, seglen);
+        case 2: return launch_jacobikc_t<K, 8, 3, 2, true, PF>(c, a, finest, zr, seglen);
+        case 3: return launch_jacobikc_t<K, 6, 4, 1, true, PF, 3, 64>(c, a, finest, zr, seglen);
+        case 4: return launch_jacobikc_t<K, 8, 3, 1, true, PF, 4, 64>(c, a, finest, zr, seglen);
+        case 5: if constexpr (K <= 4) return launch_jacobikc_t<K, 4, 6, 1, true, PF, 2, 64>(c, a, finest, zr, seglen);
+        default: return launch_jacobikc_t<K, 12, 2, 2, true, PF>(c, a, finest, zr, seglen);
     }
 }
 
 template <int K>
-int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest) {
+int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest, const JK3Range& zr, int seglen) {
     // a second plane of x staged in registers ("fuse_k_pf" 2) fits the register budget with three sweeps only
     if constexpr (K == 3) {
-        if (c->fuse_k_pf == 2) return launch_jacobikc_kp<K, 2>(c, a, finest);
+        if (c->fuse_k_pf == 2) return launch_jacobikc_kp<K, 2>(c, a, finest, zr, seglen);
     }
-    return launch_jacobikc_kp<K, 1>(c, a, finest);
+    // (two sweeps per pass: slabs only, where a pass also saves an exchange; one tile shape)
+    if constexpr (K == 2) return launch_jacobikc_t<K, 12, 4, 1, true, 1>(c, a, finest, zr, seglen);
+    else return launch_jacobikc_kp<K, 1>(c, a, finest, zr, seglen);
 }
 
-// out = K Jacobi sweeps applied to x (3 <= K <= 5), whole levels
-int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, const double* f_rows, double* out_rows) {
+// out = K Jacobi sweeps applied to x (2 <= K <= 5) on the owned planes [zr) of the level (null: all of them); on slabs the
+// level's K halo planes of x and K - 1 of f must be valid
+int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, const double* f_rows, double* out_rows,
+                    const JK3Range* zr = nullptr, int seglen = 0) {
     JK3Args a{};
     a.x = x_rows; a.f = f_rows; a.out = out_rows;
     a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead; a.ncls = L.ncls; a.cmain = L.cmain;
     for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
     a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.omega = c->omega;
-    a.plo = a.phi = 0;
+    const bool dist = !L.replicated && c->comm.active();
+    a.plo = dist && c->comm.rank > 0 ? K : 0;
+    a.phi = dist && c->comm.rank + 1 < c->comm.world ? K : 0;
+    if (dist && (L.hd < K || L.cls_halo != 1)) return fail("the level's halos are not prepared for that many sweeps per pass");
     a.force_form = c->timing_force_form;
+    const JK3Range whole{0, L.g.nk, 0, 0};
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     switch (K) {
-        case 3: return launch_jacobikc_k<3>(c, a, finest);
-        case 4: return launch_jacobikc_k<4>(c, a, finest);
-        case 5: return launch_jacobikc_k<5>(c, a, finest);
-        default: return fail("sweeps per pass must be in 3..5");
+        case 2: return launch_jacobikc_k<2>(c, a, finest, zr ? *zr : whole, seglen);
+        case 3: return launch_jacobikc_k<3>(c, a, finest, zr ? *zr : whole, seglen);
+        case 4: return launch_jacobikc_k<4>(c, a, finest, zr ? *zr : whole, seglen);
+        case 5: return launch_jacobikc_k<5>(c, a, finest, zr ? *zr : whole, seglen);
+        default: return fail("sweeps per pass must be in 2..5");
     }
 }
 
@@ -1457,6 +1583,53 @@ int smooth(mg_context* c, int level, int nw) {
     if (fused && nw > 1) {
         if (dist) MG_TRY(vec_alloc(c, L, &L.sw));
         plan = jacobi2_plan(c, L, dist, lo_end * S + L.g.plane + L.g.nx + 2);
+    }
+    // Slabs with room for K halo planes ("halo_depth"): K sweeps per pass AND per exchange -- K planes of the iterate travel
+    // once per pass (the same volume as one plane per sweep) and the march relaxes the neighbours' K - 1 planes next to the
+    // slab itself, so there is no boundary chain: two launches and one grouped send / receive per K sweeps.  With the
+    // overlap on, the planes the neighbours wait for are relaxed first (one launch), and travel on the communication
+    // stream while a second launch relaxes the rest.  (Everything that decides is the same on every rank.)
+    if (dist && nw >= 2 && c->fuse_k >= 3 && c->fuse_sweeps && c->fuse_classes && c->use_classes && c->use_sdia && L.hd >= 2 &&
+        c->halo_planes == 1 && !L.flat && L.g.nx >= 32 && L.g.ny >= 32 &&
+        min_slab_rows(L) >= std::max<int64_t>(8 * L.g.plane, c->fuse_k_slab_min_rows)) {
+        if (L.cls_halo == 0) MG_TRY(ensure_class_halos(c, L));
+        if (L.cls_halo == 1) {
+            const int kmax = std::min(std::min(c->fuse_k, 5), L.hd);
+            auto next_k = [&](int left) -> int {
+                if (left < 2) return 0;
+                const int k = left >= kmax + 2 || left == kmax ? kmax : left == kmax + 1 ? kmax - 1 : left;
+                return std::max(2, std::min(k, kmax));
+            };
+            const bool lo = c->comm.rank > 0, hi = c->comm.rank + 1 < c->comm.world;
+            const int nk = L.g.nk;
+            int left = nw, k = next_k(left);
+            MG_TRY(exchange_halo(c, L, L.f, nullptr, std::max(1, kmax - 1)));
+            MG_TRY(exchange_halo(c, L, L.v, nullptr, k));
+            while (k) {
+                const int kn = next_k(left - k);                    // the pass after this one
+                const int e = kn ? kn : c->halo_planes;             // planes of the new iterate the neighbours need next
+                const bool split = c->overlap && c->comm_stream && min_slab_rows(L) >= c->overlap_min_rows &&
+                                   min_slab_rows(L) >= (int64_t)(4 * e + 8) * L.g.plane;
+                if (split) {
+                    const int lob = lo ? e : 0, hib = hi ? e : 0;
+                    const JK3Range edge{0, lob, nk - hib, nk}, rest{lob, nk - hib, 0, 0};
+                    MG_TRY(launch_jacobikc(c, L, k, L.v.rows, L.f.rows, L.v2.rows, &edge, e));
+                    HIP_TRY(hipEventRecord(c->ev_boundary, c->stream));
+                    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+                    MG_TRY(exchange_halo(c, L, L.v2, c->comm_stream, e));
+                    HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+                    MG_TRY(launch_jacobikc(c, L, k, L.v.rows, L.f.rows, L.v2.rows, &rest));
+                    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+                } else {
+                    MG_TRY(launch_jacobikc(c, L, k, L.v.rows, L.f.rows, L.v2.rows));
+                    MG_TRY(exchange_halo(c, L, L.v2, nullptr, e));
+                }
+                std::swap(L.v, L.v2);
+                left -= k;
+                k = kn;
+            }
+            nw = left;
+        }
     }
     if (!dist && fused && nw >= 3 && sweepsk_ok(c, L)) {
         // whole levels: K sweeps per pass while that leaves no single sweep over (50 = 12 x 4 + 2, 7 = 4 + 3, 5 = 3 + 2)
@@ -2093,7 +2266,7 @@ int build_row_classes(mg_context* c, Level& L) {
     HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + val_bytes + int_bytes, c->stream));
     int* const ints = reinterpret_cast<int*>(scratch.p + tag_bytes + val_bytes);
     // padded like the vectors (vec_reach) so that the pass can read whole tiles around the level unpredicated
-    const int64_t cls_lead = ((std::max(L.mlead, vec_reach(L)) + 255) / 256) * 256;
+    const int64_t cls_lead = ((std::max(L.mlead, vec_reach(L) + (int64_t)L.hd * L.g.plane) + 255) / 256) * 256;
     const int64_t cls_rows = cls_lead + L.nloc + cls_lead + 512;
     unsigned char* cls = nullptr;
     double* ctab = nullptr;
@@ -2630,6 +2803,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         for (auto& L : c->L)
             if (L.set) return fail("halo_planes must be chosen before level set-up");
         c->halo_planes = (int)value;
+    } else if (k == "halo_depth") {
+        if (value < 0 || value > 5) return fail("halo_depth must be in 0..5");
+        for (auto& L : c->L)
+            if (L.set) return fail("halo_depth must be chosen before level set-up");
+        c->halo_depth = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0;
     } else if (k == "overlap_min_rows") {
@@ -2695,6 +2873,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_k_shape") {
         if (value < 0 || value > 5) return fail("fuse_k_shape must be 0..5");
         c->fuse_k_shape = (int)value;
+    } else if (k == "fuse_k_slab_min_rows") {
+        c->fuse_k_slab_min_rows = value;
     } else if (k == "fuse_k_pf") {
         if (value != 1 && value != 2) return fail("fuse_k_pf must be 1 or 2");
         c->fuse_k_pf = (int)value;
@@ -2865,8 +3045,9 @@ int mg_level_slab(mg_handle c, int level, int N, int64_t* row0, int64_t* n_local
     MG_TRY(setup_geometry(c, tmp, level, N));
     if (row0) *row0 = tmp.row0;
     if (n_local) *n_local = tmp.nloc;
-    if (halo_lo) *halo_lo = tmp.halo_lo;
-    if (halo_hi) *halo_hi = tmp.halo_hi;
+    // (what the rows may couple to: "halo_planes" planes, however many the vectors have room for)
+    if (halo_lo) *halo_lo = tmp.halo_lo ? (int64_t)c->halo_planes * tmp.g.plane : 0;
+    if (halo_hi) *halo_hi = tmp.halo_hi ? (int64_t)c->halo_planes * tmp.g.plane : 0;
     return 0;
 }
 
@@ -3478,7 +3659,9 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             const bool forced = k.find(":form") != std::string::npos;
             if (!sweepsk_ok(c, L, forced || k.find('!') != std::string::npos)) return fail("level does not use the K-sweep pass");
             c->timing_force_form = forced ? k.back() - '0' : -1;
-            const int rc = launch_jacobikc(c, L, std::min(c->fuse_k, 5), L.v.rows, L.f.rows, L.v2.rows);
+            const bool slab = !L.replicated && c->comm.active();
+            if (slab && L.cls_halo != 1) return fail("the slab's class halos are not built yet (first smoother call)");
+            const int rc = launch_jacobikc(c, L, std::min(std::min(c->fuse_k, 5), slab ? L.hd : 5), L.v.rows, L.f.rows, L.v2.rows);
             c->timing_force_form = -1;
             return rc;
         }

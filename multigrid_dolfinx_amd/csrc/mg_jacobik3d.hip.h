@@ -55,7 +55,9 @@ struct JK3Args {
     double omega;
     int nx, ny, nz;             // nz: owned planes
     int plo, phi;               // halo planes below / above whose rows exist on a neighbour (0: the level ends here)
-    int ntx, nty, seglen;
+    // work items: tiles x plane segments of `seglen` planes; the launch covers the planes [za0, za1) and then [zb0, zb1)
+    // (slabs: the planes the neighbours wait for in one launch, the rest in another; whole levels: [0, nz) and nothing)
+    int ntx, nty, seglen, za0, za1, zb0, zb1;
     unsigned nitems, xcd_chunk;
     int force_form;             // -1; timing experiments (mg_time_kernel only, results are wrong): every step in form 0 / 1 / 2
 };
@@ -100,7 +102,9 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     const int seg = (int)(id / ntile);
     const unsigned tt = id % ntile;
     const int tiy = (int)(tt / (unsigned)a.ntx), tix = (int)(tt % (unsigned)a.ntx);
-    const int z0 = seg * a.seglen, z1 = min(a.nz, z0 + a.seglen);
+    const int nsa = (a.za1 - a.za0 + a.seglen - 1) / a.seglen;
+    const int z0 = seg < nsa ? a.za0 + seg * a.seglen : a.zb0 + (seg - nsa) * a.seglen;
+    const int z1 = min(seg < nsa ? a.za1 : a.zb1, z0 + a.seglen);
     if (z1 <= z0) return;
     const int tx0 = tix * WI - K, ty0 = tiy * HY - (K - 1);   // grid position of cell (0, 0)
 
@@ -422,9 +426,11 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             fast |= (unsigned long long)m << (K * NC);
         }
         // which form: 0 = interior stencil everywhere in this wave's cells of the planes k .. k+K, 1 = classes that depend on
-        // the lane only -- both only where every row the step touches exists (planes k-1 .. k+K+1 through sh) --, 2 = general
+        // the lane only -- both only where every row the step touches exists (planes k-1 .. k+K+1 through sh) or lies on a
+        // neighbouring slab (there a level's values beyond its plane range are wrong instead of zero, and reach no
+        // result) --, 2 = general
         int form = 2;
-        if (k >= 1 && k + K + 1 < a.nz) {
+        if ((a.plo > 0 || k >= 1) && (a.phi > 0 || k + K + 1 < a.nz)) {
             if (fast == ALLFAST) {
                 form = 0;
             } else {

@@ -43,6 +43,11 @@ def main(world, dim, lo, hi, c, mu, replicate_below, overlap):
             h = DeviceHierarchy.synthetic(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, **tune)
             info = h.level_info(hi)
             assert not info["replicated"] and info["n_local"] < info["n_global"]
+            if os.environ.get("MG_TEST_EXPECT_KSLAB"):
+                # the K-sweep march really runs on this slab (its class halos get built at the first smoother call)
+                h.zero_vector(hi, "v")
+                h.smooth(hi, mu)
+                assert h.time_kernel("jacobik3", hi, 1) > 0
             h.prepare_cycle(hi)
             phase(h)
             h.zero_vector(hi, "v")

@@ -150,3 +150,37 @@ def test_p2_levels_on_slabs_with_two_plane_halos(world, dim, lo, hi, c, rep, ove
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "OK" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mu,depth,fuse_k,overlap", [(2, 7, 4, 4, 1), (4, 9, 4, 4, 1), (3, 5, 3, 3, 0), (2, 11, 5, 5, 1), (4, 4, 2, 4, 1),
+                                                          (3, 6, 4, 4, 1)])
+def test_k_sweep_passes_on_slabs_match_single_handle(world, mu, depth, fuse_k, overlap):
+    """`halo_depth` = K: the K-sweep march on slabs (129^3 and 65^3 unknowns, both distributed).  K planes of the iterate
+    travel once per K sweeps, the slab relaxes its neighbours' K - 1 planes next to it itself -- through their row classes,
+    translated into its own dictionary at set-up --, so there is no boundary chain.  2-4 ranks as threads over the
+    in-process RCCL stand-in (asynchronous, event-ordered copies), with the boundary-planes-first overlap and without;
+    sweep counts that split into passes of different sizes (7 = 4 + 3, 9 = 4 + 3 + 2, 11 = 5 + 4 + 2 ...), `halo_depth` 2
+    (pairs only).  Bit-identical to the single-handle run."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
+    tune = f"halo_depth={depth},fuse_k={fuse_k},fuse_min_rows=0,fuse_k_slab_min_rows=0"
+    env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_TUNE=tune, MG_TEST_EXPECT_KSLAB="1")
+    out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), "3", "2", "4", "8", str(mu), "0",
+                          str(overlap)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "OK" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mu,depth", [(2, 7, 4), (3, 5, 3)])
+def test_k_sweep_passes_on_slabs_over_the_host_staged_transport(world, mu, depth):
+    """The same through the callback transport, one PROCESS per rank sharing the GPU (edge and interior ranks, the class
+    translation and every exchange over gloo): bit-identical to the single handle."""
+    from tests.dist_workers import gpu_slab_worker
+    _spawn(gpu_slab_worker, world, 3, 2, 4, 8, mu, 0, "gen", {"halo_depth": depth, "fuse_min_rows": 0, "fuse_k_slab_min_rows": 0})

@@ -624,23 +624,74 @@ def test_direct_solver_rejects_matrices_it_cannot_factor():
             assert "did not converge" in str(exc)
 
 
-def test_3d_n128_reference_parameters_match_oracle():
+_N128 = {}
+
+
+def _n128_oracle():
+    """V(50,50) on the 129^3 hierarchy by the oracle (once per session: ~half a minute of SciPy)."""
+    if not _N128:
+        from oracle.mg_oracle import Oracle
+        bag = poisson.make_hierarchy(3, 2, 4, c=8, mu1=50, mu2=50)
+        orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=3)
+        f = bag.b_dict[4]
+        want = orc.v_cycle(orc.A_jacobi_sp_dict[4], np.zeros_like(f), f)
+        r = f - bag.A_sp_dict[4][0].dot(want)
+        _N128.update(want=want, res=float(np.linalg.norm(r)))
+    return _N128["want"], _N128["res"]
+
+
+@pytest.mark.parametrize("tuning", [dict(), dict(fuse_min_rows=0, march_min_rows=0), dict(fuse_min_rows=0, march_min_rows=0, fuse_k=0),
+                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_k=3, fuse_k_shape=0),
+                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_k=5, fuse_k_shape=4),
+                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_classes=0, class_sweeps=0)])
+def test_3d_n128_reference_parameters_match_oracle(tuning):
     """The largest 3-D oracle comparison that fits a test budget: 129^3 unknowns, 3 levels (coarsest 33^3 =
     BASELINE's coarsest grid), the reference's V(50,50), omega = 2/3.  3-D is parity-unpinned (no reference);
-    this pins the HIP path to the CPU restatement at the north-star tolerance."""
+    this pins the HIP path to the CPU restatement at the north-star tolerance.  With the size thresholds at zero the
+    kernels that the headline sizes run -- the K-sweep march `sdia_jacobikc`, the two-sweep passes `sdia_jacobi2c` /
+    `sdia_jacobi2p`, the one-sweep march `sdia_sweep1c` -- face the oracle themselves, not only the slice kernels they
+    are bit-identical to (default thresholds: 129^3 rows stay below them)."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
-    from oracle.mg_oracle import Oracle
-    bag = poisson.make_hierarchy(3, 2, 4, c=8, mu1=50, mu2=50)
-    orc = Oracle(bag, {l: L.grid_index for l, L in bag.levels.items()}, dim=3)
-    f = bag.b_dict[4]
-    want = orc.v_cycle(orc.A_jacobi_sp_dict[4], np.zeros_like(f), f)
-    r = f - bag.A_sp_dict[4][0].dot(want)
-    with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=50, mu2=50) as dev:
+    want, res_want = _n128_oracle()
+    with DeviceHierarchy.synthetic(3, 2, 4, c=8, mu1=50, mu2=50, **tuning) as dev:
+        if tuning:
+            assert dev.time_kernel("jacobi2", 4, 1) > 0             # the smoother does run the march kernels on this level
         dev.zero_vector(4, "v")
         res = dev.vcycle(4, 1, residuals=True)
         got = dev.get_vector(4, "v")
     assert rel_l2(got, want) <= TOL_ITER
-    assert abs(res[0] - np.linalg.norm(r)) <= TOL_ITER * np.linalg.norm(r)
+    assert abs(res[0] - res_want) <= TOL_ITER * res_want
+
+
+def test_p2_plane_march_faces_the_oracle_directly():
+    """BASELINE config 5's kernels at a size the oracle still does in seconds: the 65^3-point P2 lattice (3 levels, nine-colour
+    Gauss-Seidel V(2,2), P2 transfer pair) with `lattice_march_min_rows` 0, so that `lat_march` -- not only the gathering
+    kernel it is bit-identical to -- is compared with oracle/mg_oracle.py at the north-star tolerance.  No reference
+    implementation exists for P2 / Gauss-Seidel: parity unpinned, the oracle is the only independent check."""
+    import types
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import Oracle
+    dim, lo, hi, c = 3, 1, 3, 8                        # lattices of 16, 32, 64 steps per dimension
+    levels = {l: poisson.p2_level(c * 2 ** l // 2, dim) for l in range(lo, hi + 1)}
+    bag = types.SimpleNamespace(
+        mesh_dof_list_dict={}, element_size={l: 1.0 / L.N for l, L in levels.items()}, coarsest_level_elements_per_dim=c,
+        coarsest_level=lo, finest_level=hi, A_sp_dict={l: (L.A, l) for l, L in levels.items()}, A_jacobi_sp_dict={},
+        b_dict={l: L.b for l, L in levels.items()}, mu0=1, mu1=2, mu2=2, omega=1.0,
+        residual_per_V_cycle_finest=[], error_per_V_cycle_finest=[], u_exact_fine=None, V_fine_dolfx=None, levels=levels)
+    orc = Oracle(bag, {l: L.grid_index for l, L in levels.items()}, dim=dim)
+    orc.prolongation_table = poisson.p2_prolongation_table(dim)
+    orc.restriction_table = poisson.p2_restriction_table(dim)
+    f = bag.b_dict[hi]
+    want = orc.v_cycle(orc.A_jacobi_sp_dict[hi], np.zeros_like(f), f, smoother="mcgs", restriction="table")
+    r_want = float(np.linalg.norm(f - bag.A_sp_dict[hi][0].dot(want)))
+    for march in (1, 0):
+        with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=2, mu2=2, omega=1.0, transfers="p2", restriction="table",
+                                          lattice_march=march, lattice_march_min_rows=0) as dev:
+            dev.zero_vector(hi, "v")
+            res = dev.vcycle(hi, 1, residuals=True)
+            got = dev.get_vector(hi, "v")
+        assert rel_l2(got, want) <= TOL_ITER, march
+        assert abs(res[0] - r_want) <= TOL_ITER * r_want, march
 
 
 @pytest.mark.parametrize("dim,c,seed", [(2, 5, None), (2, 7, 3), (3, 3, None), (3, 5, 8), (2, 1, None), (3, 1, 2)])
