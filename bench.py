@@ -47,7 +47,7 @@ def kernel_source_sha():
     import hashlib
     hsh = hashlib.sha256()
     base = os.path.join(ROOT, "multigrid_dolfinx_amd", "csrc")
-    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_lattice.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
+    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_jacobik3d.hip.h", "mg_lattice.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
         try:
             hsh.update(open(os.path.join(base, name), "rb").read())
         except OSError:
@@ -382,11 +382,20 @@ def main():
     jac_ms = h.time_kernel("jacobi", hi, args.kernel_reps)
     res_ms = h.time_kernel("residual", hi, args.kernel_reps)
     gs_ms = h.time_kernel("gs", hi, max(2, args.kernel_reps // 4)) if p2 else None
-    try:        # the smoother pairs sweeps on this level (mg_jacobi2.hip.h): that launch is the dominant one
-        pair_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
+    multi_k, small, march_k = 0, False, 0
+    tuned = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune}
+    try:        # the smoother runs K sweeps per pass on this level (mg_jacobik3d.hip.h): that launch is the dominant one
+        pair_ms = h.time_kernel("jacobik3", hi, args.kernel_reps)
+        multi_k = march_k = min(tuned.get("fuse_k", 4), 5)
     except Exception:
         pair_ms = None
-    multi_k, small = 0, False
+    pair2_ms = None
+    try:        # ... and pairs of sweeps where that does not apply / for what is left over (mg_jacobi2.hip.h)
+        pair2_ms = h.time_kernel("jacobi2", hi, args.kernel_reps)
+    except Exception:
+        pass
+    if pair_ms is None:
+        pair_ms = pair2_ms
     if pair_ms is None:
         try:    # levels of a few thousand rows: all mu sweeps of a smoother call in one launch (sdia_jacobi_small)
             pair_ms = h.time_kernel("jacobi_small", hi, args.kernel_reps)
@@ -436,10 +445,16 @@ def main():
                      "ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif small:
         kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
+    elif march_k:
+        shape = {0: "12, 2, 2", 1: "12, 4, 1", 2: "8, 3, 2", 3: "6, 4, 1", 4: "8, 3, 1", 5: "4, 6, 1"}[tuned.get("fuse_k_shape", 1)]
+        kernel_id = f"sdia_jacobikc_finest<{march_k}, {shape}>"
     elif multi_k:
         kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
     elif pair_ms:
-        kernel_id = ("sdia_jacobi2c_finest<12, 2>" if dom_classes else "sdia_jacobi2_finest<2, 8, 2, false>")
+        # (without row classes: the round-2 structure of the pass on the stored rows, unless "fuse_plain" 1 asks for round 1's)
+        plain = {0: "sdia_jacobi2p_finest<2, 12, 1>", 1: "sdia_jacobi2p_finest<2, 8, 2>", 2: "sdia_jacobi2p_finest<2, 16, 1>"}[
+            tuned.get("fuse_plain_shape", 0)] if tuned.get("fuse_plain", 2) == 2 else "sdia_jacobi2_finest<2, 8, 2, false>"
+        kernel_id = "sdia_jacobi2c_finest<12, 2>" if dom_classes else plain
     elif info["symmetric_diagonals"]:
         kernel_id = ("sdia_cls_jacobi_finest<%d, 2, true>" % info["symmetric_diagonals"]) if dom_classes else \
                     ("sdia_jacobi_finest<%d, 2, true>" % info["symmetric_diagonals"])
@@ -460,7 +475,8 @@ def main():
             elif entry.get("kernel_source_sha") != src_sha:
                 traffic_note = f"kernel sources changed since {entry.get('profile')} was taken"
             else:
-                traffic, traffic_note = entry["hbm_bytes_per_launch"], entry.get("profile")
+                traffic = entry["hbm_bytes_per_launch"]
+                traffic_note = f"{entry.get('profile')}: FETCH_SIZE x 2 + WRITE_SIZE at the L2 / fabric boundary (Infinity Cache hits included): an upper bound on the HBM bytes"
         except Exception as exc:           # noqa: BLE001
             traffic_note = f"profiles/traffic.json unreadable: {exc}"
 
@@ -473,7 +489,7 @@ def main():
         try:
             k_plain = max(1, min(args.steps, 5))
             value_plain = k_plain / timed_cycles(h, rv, hi, 1, k_plain)
-            if pair_ms and not multi_k:
+            if pair_ms and (not multi_k or march_k):
                 pair_plain_ms = h.time_kernel("jacobi2", hi, max(2, args.kernel_reps // 2))
         finally:
             h.set_tuning("fuse_classes", 1)
@@ -497,7 +513,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) omega={args.omega:.4f}, "
-                                   f"P2 prolongation and its transpose as restriction (injection on slabs), PCG coarsest solve, up to 51 "
+                                   f"P2 prolongation and its transpose as restriction (injection on slabs), exact block-LU coarsest solve, up to 51 "
                                    f"entries per row; "
                                    f"no reference implementation exists for this configuration (parity unpinned)" if p2 else
                                    f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "
@@ -527,6 +543,8 @@ def main():
                          # what crosses the L2/fabric boundary per second (PMC): includes tile rims and re-reads
                          "traffic_GBs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "pair_pass_kernel_ms": pair2_ms,
+                         "pair_pass_frac": (fmt_row * n_loc / (pair2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pair2_ms else None,
                          "single_sweep_kernel_ms": jac_ms,
                          "single_sweep_frac": format_bytes_per_row(classes_in_sweep) * n_loc / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "residual_kernel_ms": res_ms,

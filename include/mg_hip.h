@@ -228,6 +228,8 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          (levels of at most 64 row classes) (1: measured best)
  *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
  *     "fuse_k_slab_min_rows"  ... on slabs (below): levels whose smallest slab has at least this many rows (1048576)
+ *     "fuse_k_slab_min_sweeps"  ... and smoother calls of at least this many sweeps (4)
+ *     "fuse_k_small_tiles" 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than the GPU has CUs (1)
  *     "fuse_k_pf"          register sets for the planes of x that arrive: 2 = a second set keeps x staged one step longer
  *                          (three sweeps per pass only) (1: measured no slower)
  *     "fuse_k_dpp"         0 = the -1 / +1 neighbours of that march come through LDS instead of the neighbouring lanes'

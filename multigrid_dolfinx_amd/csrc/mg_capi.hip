@@ -265,6 +265,8 @@ struct mg_context {
     int timing_force_form = -1;     // mg_time_kernel("jacobik3:formN"): every step of the K-sweep pass in one form (wrong results; how fast
                                     // each form is by itself)
     int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
+    int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
+    int fuse_k_small_tiles = 1;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
@@ -1315,7 +1317,13 @@ template <int K, int PF>
 int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest, const JK3Range& zr, int seglen) {
     if (!c->fuse_k_dpp) return launch_jacobikc_t<K, 12, 2, 2, false, PF>(c, a, finest, zr, seglen);     // (experiment: -1 / +1 neighbours through LDS)
     // shapes 3..5: 64 x 24 tiles, two workgroups per CU (class table of 64 rows); levels with more classes take shape 1
-    const int shape = c->fuse_k_shape >= 3 && a.ncls > 64 ? 1 : c->fuse_k_shape;
+    int shape = c->fuse_k_shape >= 3 && a.ncls > 64 ? 1 : c->fuse_k_shape;
+    // planes with fewer 64 x 48 tiles than the GPU has CUs (the 513^2 and 257^2 planes of a slab's coarser levels): half
+    // as tall tiles, two workgroups per CU
+    if (shape == 1 && a.ncls <= 64 && K <= 4 && c->fuse_k_small_tiles) {
+        constexpr int WI = 64 - 2 * K, HY = 48 - 2 * K + 2;
+        if ((int64_t)((a.nx + WI - 1) / WI) * ((a.ny + HY - 1) / HY) < std::max(1, c->prop.multiProcessorCount)) shape = 4;
+    }
     switch (shape) {
         case 1: return launch_jacobikc_t<K, 12, 4, 1, true, PF>(c, a, finest, zr, seglen);
         case 2: return launch_jacobikc_t<K, 8, 3, 2, true, PF>(c, a, finest, zr, seglen);
@@ -1589,7 +1597,7 @@ int smooth(mg_context* c, int level, int nw) {
     // slab itself, so there is no boundary chain: two launches and one grouped send / receive per K sweeps.  With the
     // overlap on, the planes the neighbours wait for are relaxed first (one launch), and travel on the communication
     // stream while a second launch relaxes the rest.  (Everything that decides is the same on every rank.)
-    if (dist && nw >= 2 && c->fuse_k >= 3 && c->fuse_sweeps && c->fuse_classes && c->use_classes && c->use_sdia && L.hd >= 2 &&
+    if (dist && nw >= c->fuse_k_slab_min_sweeps && c->fuse_k >= 3 && c->fuse_sweeps && c->fuse_classes && c->use_classes && c->use_sdia && L.hd >= 2 &&
         c->halo_planes == 1 && !L.flat && L.g.nx >= 32 && L.g.ny >= 32 &&
         min_slab_rows(L) >= std::max<int64_t>(8 * L.g.plane, c->fuse_k_slab_min_rows)) {
         if (L.cls_halo == 0) MG_TRY(ensure_class_halos(c, L));
@@ -2875,6 +2883,11 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_k_shape = (int)value;
     } else if (k == "fuse_k_slab_min_rows") {
         c->fuse_k_slab_min_rows = value;
+    } else if (k == "fuse_k_slab_min_sweeps") {
+        if (value < 2) return fail("fuse_k_slab_min_sweeps must be at least 2");
+        c->fuse_k_slab_min_sweeps = (int)value;
+    } else if (k == "fuse_k_small_tiles") {
+        c->fuse_k_small_tiles = value != 0;
     } else if (k == "fuse_k_pf") {
         if (value != 1 && value != 2) return fail("fuse_k_pf must be 1 or 2");
         c->fuse_k_pf = (int)value;

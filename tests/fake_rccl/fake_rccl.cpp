@@ -123,7 +123,12 @@ ncclResult_t flush_group() {
             w->cv.wait(lk, [&] { return msg->taken; });
         }
         if (hipStreamWaitEvent(op.stream, msg->consumed, 0) != hipSuccess) return ncclUnhandledCudaError;
-        // events are leaked on purpose until process exit (they may still be pending on a stream)
+        // The receiver is done with the message (`taken` is set after its last use).  Destroying an event that a stream still
+        // waits for is legal -- its resources go when it has completed --, and it keeps the number of live events bounded:
+        // round 2 leaked two per message, tens of thousands per probe run (see DESIGN.md section 6 on the profiler crash).
+        (void)hipEventDestroy(msg->ready);
+        (void)hipEventDestroy(msg->consumed);
+        delete msg;
     }
     t_ops.clear();
     return ncclSuccess;

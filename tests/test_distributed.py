@@ -169,7 +169,7 @@ def test_k_sweep_passes_on_slabs_match_single_handle(world, mu, depth, fuse_k, o
     lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(lib):
         subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
-    tune = f"halo_depth={depth},fuse_k={fuse_k},fuse_min_rows=0,fuse_k_slab_min_rows=0"
+    tune = f"halo_depth={depth},fuse_k={fuse_k},fuse_min_rows=0,fuse_k_slab_min_rows=0,fuse_k_slab_min_sweeps=2"
     env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_TUNE=tune, MG_TEST_EXPECT_KSLAB="1")
     out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), "3", "2", "4", "8", str(mu), "0",
                           str(overlap)], env=env, capture_output=True, text=True, timeout=600)
@@ -183,4 +183,4 @@ def test_k_sweep_passes_on_slabs_over_the_host_staged_transport(world, mu, depth
     """The same through the callback transport, one PROCESS per rank sharing the GPU (edge and interior ranks, the class
     translation and every exchange over gloo): bit-identical to the single handle."""
     from tests.dist_workers import gpu_slab_worker
-    _spawn(gpu_slab_worker, world, 3, 2, 4, 8, mu, 0, "gen", {"halo_depth": depth, "fuse_min_rows": 0, "fuse_k_slab_min_rows": 0})
+    _spawn(gpu_slab_worker, world, 3, 2, 4, 8, mu, 0, "gen", {"halo_depth": depth, "fuse_min_rows": 0, "fuse_k_slab_min_rows": 0, "fuse_k_slab_min_sweeps": 2})

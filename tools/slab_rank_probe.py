@@ -49,6 +49,22 @@ for rank in (sorted({0, world // 2, world - 1}) if only is None else [only]):
     h = DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=mu, mu2=mu,
                                   comm=lambda hh: hh.set_comm_rccl(rank, world, buf.raw, replicate_below=1 << 22), **tune)
     t = timed(h)
+    if os.environ.get("MG_PROBE_LEVELS"):          # where the time goes: one smoother call of mu sweeps per distributed level
+        for level in range(hi, 2, -1):
+            if h.level_info(level)["replicated"]:
+                break
+            h.smooth(level, mu)
+            h.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                h.smooth(level, mu)
+            h.sync()
+            print(f"    level {level}: smooth({mu}) {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", flush=True)
+            for name in ("jacobik3", "jacobi2", "jacobi"):
+                try:
+                    print(f"        one launch of {name}: {h.time_kernel(name, level, 5):.3f} ms", flush=True)
+                except Exception as exc:                     # noqa: BLE001
+                    print(f"        {name}: {exc}", flush=True)
     print(f"rank {rank} of {world} alone: {t * 1e3:.2f} ms per cycle = {world * t / t_single:.3f} x its share of the single handle"
           f" (graph replays {h.counters()['graph_replays']}, tuning {tune})", flush=True)
     worst = max(worst, t)
