@@ -229,7 +229,11 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
  *     "fuse_k_slab_min_rows"  ... on slabs (below): levels whose smallest slab has at least this many rows (1048576)
  *     "fuse_k_slab_min_sweeps"  ... and smoother calls of at least this many sweeps (4)
- *     "fuse_k_small_tiles" 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than the GPU has CUs (1)
+ *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep the pairs (67108864)
+ *     "fuse_k4_min_rows"   ... more than three sweeps per pass only on levels with at least this many rows (536870912:
+ *                          measured, four sweeps pay on 1025^3 rows, three on 513^3, pairs below)
+ *     "fuse_k_small_tiles" 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than the GPU has CUs (0:
+ *                          measured slower)
  *     "fuse_k_pf"          register sets for the planes of x that arrive: 2 = a second set keeps x staged one step longer
  *                          (three sweeps per pass only) (1: measured no slower)
  *     "fuse_k_dpp"         0 = the -1 / +1 neighbours of that march come through LDS instead of the neighbouring lanes'

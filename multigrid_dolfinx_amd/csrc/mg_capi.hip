@@ -266,7 +266,9 @@ struct mg_context {
                                     // each form is by itself)
     int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
     int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
-    int fuse_k_small_tiles = 1;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
+    int64_t fuse_k_min_rows = (int64_t)1 << 26;        // ... on whole levels with at least this many rows (fewer: pairs)
+    int64_t fuse_k4_min_rows = (int64_t)1 << 29;       // ... more than three sweeps per pass on levels with at least this many rows
+    int fuse_k_small_tiles = 0;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
     std::vector<const void*> large_lds_kernels;     // kernels whose dynamic-LDS limit has been raised (allow_large_lds)
@@ -1267,7 +1269,14 @@ int ensure_class_halos(mg_context* c, Level& L) {
 bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     if (c->fuse_k < 3 || !L.cls || !c->fuse_classes) return false;
     if (!L.replicated && c->comm.active() && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
+    if (!ignore_size && L.nloc < c->fuse_k_min_rows) return false;
     return fused_sweeps_ok(c, L, ignore_size) && L.g.nk >= 8;
+}
+
+// sweeps per pass on a whole level: measured on one MI355X (profiles/r03_ksweep_levels.txt), four pay on 1025^3 rows, three
+// on 513^3, pairs (mg_jacobi2.hip.h) below
+int sweepsk_max(const mg_context* c, const Level& L) {
+    return std::min(std::min(c->fuse_k, 5), L.nloc >= c->fuse_k4_min_rows ? 5 : 3);
 }
 
 // plane ranges of one launch of the march: [za0, za1) and then [zb0, zb1)
@@ -1641,7 +1650,7 @@ int smooth(mg_context* c, int level, int nw) {
     }
     if (!dist && fused && nw >= 3 && sweepsk_ok(c, L)) {
         // whole levels: K sweeps per pass while that leaves no single sweep over (50 = 12 x 4 + 2, 7 = 4 + 3, 5 = 3 + 2)
-        const int kmax = std::min(c->fuse_k, 5);
+        const int kmax = sweepsk_max(c, L);
         int left = nw;
         while (left >= 3) {
             int k = left >= kmax + 2 || left == kmax ? kmax : left == kmax + 1 ? kmax - 1 : left;
@@ -2886,6 +2895,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_k_slab_min_sweeps") {
         if (value < 2) return fail("fuse_k_slab_min_sweeps must be at least 2");
         c->fuse_k_slab_min_sweeps = (int)value;
+    } else if (k == "fuse_k_min_rows") {
+        c->fuse_k_min_rows = value;
+    } else if (k == "fuse_k4_min_rows") {
+        c->fuse_k4_min_rows = value;
     } else if (k == "fuse_k_small_tiles") {
         c->fuse_k_small_tiles = value != 0;
     } else if (k == "fuse_k_pf") {
@@ -3674,7 +3687,7 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             c->timing_force_form = forced ? k.back() - '0' : -1;
             const bool slab = !L.replicated && c->comm.active();
             if (slab && L.cls_halo != 1) return fail("the slab's class halos are not built yet (first smoother call)");
-            const int rc = launch_jacobikc(c, L, std::min(std::min(c->fuse_k, 5), slab ? L.hd : 5), L.v.rows, L.f.rows, L.v2.rows);
+            const int rc = launch_jacobikc(c, L, slab ? std::min(std::min(c->fuse_k, 5), L.hd) : sweepsk_max(c, L), L.v.rows, L.f.rows, L.v2.rows);
             c->timing_force_form = -1;
             return rc;
         }

@@ -194,6 +194,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     // x, the classes and the y ring of x of the planes that arrive: PF sets, taken in turn by successive steps
     double XA[NC], XB[PF == 2 ? NC : 1], hyA[M], hyB[PF == 2 ? M : 1];
     int CA[NC], CB[PF == 2 ? NC : 1];
+    double FN[PF == 2 ? NC : 1];            // (PF = 2) f of the plane after the newest of the ring, staged like x
     unsigned cw[K + 1][CW];     // class bytes of the planes k .. k+K, four cells to a register
     unsigned long long fast = 0;        // wave-uniform; bit j*NC + c: all 64 cells c of plane k+j are of class cmain
     constexpr unsigned long long ALLFAST = (NC * (K + 1) == 64) ? ~0ull : ((1ull << (NC * (K + 1))) - 1ull);
@@ -210,7 +211,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
         for (int q = 0; q < CW; ++q) cw[j][q] = 0u;
 #pragma unroll
     for (int r = 0; r < M; ++r) hyA[r] = 0.0;
-    XB[0] = 0.0; hyB[0] = 0.0; CB[0] = 0;
+    XB[0] = 0.0; hyB[0] = 0.0; CB[0] = 0; FN[0] = 0.0;
 
     // Loads are issued in slices, slice i of n between the pieces of phase B: issued in one burst (14 per wave, all twelve
     // waves at the same point of the step) they keep every wave at the vector-memory issue port in front of the barrier
@@ -228,7 +229,8 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             if ((c * n) / NC != i) continue;
             X[c] = ldd(xb, eo[c]);
             C[c] = ldc(cb, eo[c]);
-            fr[K - 1][c] = ldd(fb, eo[c]);
+            if constexpr (PF == 2) FN[c] = ldd(fb, eo[c]);
+            else fr[K - 1][c] = ldd(fb, eo[c]);
         }
         if (i == n - 1 && (wlo || whi)) {
 #pragma unroll
@@ -394,8 +396,9 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
 
     // One step: `X, C, hy` hold plane k+K (arrived).  PF = 1: when phase A has consumed them, the loads of plane k+K+1 go out
     // into the same registers and are in flight through phase B.  PF = 2: a second set `XN, CN, hyN` holds plane k+K+1, in
-    // flight since the step before; when phase A has consumed the first set it takes the second one over (a whole step
-    // after those loads went out) and the loads of plane k+K+2 go out into the second set: a plane is in flight at all times.
+    // flight since the step before (with f of plane k+K in `FN`); behind phase A the first set takes the second one over (a
+    // whole step after those loads went out) and the loads of plane k+K+2 go out into the second set: a plane is in
+    // flight at all times.
     auto step = [&](const int k, double (&X)[NC], int (&C)[NC], double (&hy)[M], double (&XN)[PF == 2 ? NC : 1],
                     int (&CN)[PF == 2 ? NC : 1], double (&hyN)[PF == 2 ? M : 1]) __attribute__((always_inline)) {
         k_plane = k; k_store = k >= z0;
@@ -470,9 +473,10 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
         if constexpr (PF == 2) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                X[c] = XN[c]; C[c] = CN[c];
+                X[c] = XN[c]; C[c] = CN[c]; fr[K - 1][c] = FN[c];
                 asm volatile("" : "+v"(X[c]));
                 asm volatile("" : "+v"(C[c]));
+                asm volatile("" : "+v"(fr[K - 1][c]));
             }
             if (wlo || whi) {
 #pragma unroll
@@ -481,7 +485,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
         }
         auto issue = [&](const int i, const int n) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF == 2) load_slice(i, n, k + K + 2, k + K, XN, CN, hyN);
+            if constexpr (PF == 2) load_slice(i, n, k + K + 2, k + K + 1, XN, CN, hyN);
             else load_slice(i, n, k + K + 1, k + K, X, C, hy);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -496,7 +500,11 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     };
 
     load_slice(0, 1, z0 - K, z0 - K - 1, XA, CA, hyA);
-    if constexpr (PF == 2) load_slice(0, 1, z0 - K + 1, z0 - K - 1, XB, CB, hyB);      // (f of the same plane once more)
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fr[K - 1][c] = FN[c];      // (the first slice's f went to the staging set)
+        load_slice(0, 1, z0 - K + 1, z0 - K, XB, CB, hyB);
+    }
     __syncthreads();
 
     for (int k = z0 - 2 * K; k < z1; ++k) step(k, XA, CA, hyA, XB, CB, hyB);

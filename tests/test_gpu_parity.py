@@ -640,10 +640,11 @@ def _n128_oracle():
     return _N128["want"], _N128["res"]
 
 
-@pytest.mark.parametrize("tuning", [dict(), dict(fuse_min_rows=0, march_min_rows=0), dict(fuse_min_rows=0, march_min_rows=0, fuse_k=0),
-                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_k=3, fuse_k_shape=0),
-                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_k=5, fuse_k_shape=4),
-                                    dict(fuse_min_rows=0, march_min_rows=0, fuse_classes=0, class_sweeps=0)])
+_SMALL = dict(fuse_min_rows=0, march_min_rows=0, fuse_k_min_rows=0, fuse_k4_min_rows=0)
+
+
+@pytest.mark.parametrize("tuning", [dict(), dict(_SMALL), dict(_SMALL, fuse_k=0), dict(_SMALL, fuse_k=3, fuse_k_shape=0),
+                                    dict(_SMALL, fuse_k=5, fuse_k_shape=4), dict(_SMALL, fuse_classes=0, class_sweeps=0)])
 def test_3d_n128_reference_parameters_match_oracle(tuning):
     """The largest 3-D oracle comparison that fits a test budget: 129^3 unknowns, 3 levels (coarsest 33^3 =
     BASELINE's coarsest grid), the reference's V(50,50), omega = 2/3.  3-D is parity-unpinned (no reference);
@@ -1222,7 +1223,8 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
         classes = make.get("row_classes", 1)
         with DeviceHierarchy.synthetic(3, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
-            dev.set_tuning("fuse_min_rows", 0)
+            for key in ("fuse_min_rows", "fuse_k_min_rows", "fuse_k4_min_rows"):       # small grids: still the march kernels
+                dev.set_tuning(key, 0)
             for k, v in tune.items():
                 dev.set_tuning(k, v)
             for level in range(lo + 1, hi + 1):
