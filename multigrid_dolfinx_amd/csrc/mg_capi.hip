@@ -1268,9 +1268,10 @@ int ensure_class_halos(mg_context* c, Level& L) {
 // and slabs whose vectors have room for K halo planes ("halo_depth").
 bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     if (c->fuse_k < 3 || !L.cls || !c->fuse_classes) return false;
-    if (!L.replicated && c->comm.active() && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
-    if (!ignore_size && L.nloc < c->fuse_k_min_rows) return false;
-    return fused_sweeps_ok(c, L, ignore_size) && L.g.nk >= 8;
+    const bool slab = !L.replicated && c->comm.active();
+    if (slab && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
+    if (!ignore_size && (slab ? min_slab_rows(L) < c->fuse_k_slab_min_rows : L.nloc < c->fuse_k_min_rows)) return false;
+    return fused_sweeps_ok(c, L, ignore_size || slab) && L.g.nk >= 8;
 }
 
 // sweeps per pass on a whole level: measured on one MI355X (profiles/r03_ksweep_levels.txt), four pay on 1025^3 rows, three
