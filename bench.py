@@ -386,7 +386,7 @@ def main():
     tuned = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune}
     try:        # the smoother runs K sweeps per pass on this level (mg_jacobik3d.hip.h): that launch is the dominant one
         pair_ms = h.time_kernel("jacobik3", hi, args.kernel_reps)
-        multi_k = march_k = min(tuned.get("fuse_k", 4), 5 if info["n_local"] >= tuned.get("fuse_k4_min_rows", 1 << 29) else 3)
+        multi_k = march_k = min(tuned.get("fuse_k", 5), 5 if info["n_local"] >= tuned.get("fuse_k4_min_rows", 0) else 3)
     except Exception:
         pair_ms = None
     pair2_ms = None
@@ -446,7 +446,7 @@ def main():
     elif small:
         kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
     elif march_k:
-        shape = {0: "12, 2, 2", 1: "12, 4, 1", 2: "8, 3, 2", 3: "6, 4, 1", 4: "8, 3, 1", 5: "4, 6, 1"}[tuned.get("fuse_k_shape", 1)]
+        shape = {0: "12, 2, 2", 1: "12, 4, 1", 2: "8, 3, 2", 3: "6, 4, 1", 4: "8, 3, 1", 5: "4, 6, 1", 6: "16, 3, 1", 7: "16, 2, 1"}[tuned.get("fuse_k_shape", 7)]
         kernel_id = f"sdia_jacobikc_finest<{march_k}, {shape}>"
     elif multi_k:
         kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"

@@ -222,16 +222,15 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_nontemporal"   streaming loads in that pass (0: measured slower)
  *     "fuse_k"             Jacobi sweeps per pass of the K-sweep march (mg_jacobik3d.hip.h) on whole seven-point levels with
  *                          row classes: a smoother call of nw sweeps (multigrid.py:223-228) runs as passes of 3 .. "fuse_k"
- *                          sweeps and at most one pair; 0 .. 2 = pairs only (4); bit-identical to single sweeps
+ *                          sweeps and at most one pair (50 = 10 x 5); 0 .. 2 = pairs only (5); bit-identical to single sweeps
  *     "fuse_k_shape"       tile of that march: 0 = 128 x 24 cells (12 waves x 2 grid lines), 1 = 64 x 48 (12 waves x 4 lines),
  *                          2 = 128 x 24 (8 waves x 3 lines), 3 / 4 / 5 = 64 x 24 by 6 / 8 / 4 waves with two workgroups per CU
- *                          (levels of at most 64 row classes) (1: measured best)
+ *                          (levels of at most 64 row classes), 6 / 7 = 64 x 48 / 64 x 32 by 16 waves (7: no register spills up to five sweeps, measured best)
  *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
  *     "fuse_k_slab_min_rows"  ... on slabs (below): levels whose smallest slab has at least this many rows (1048576)
  *     "fuse_k_slab_min_sweeps"  ... and smoother calls of at least this many sweeps (4)
- *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep the pairs (67108864)
- *     "fuse_k4_min_rows"   ... more than three sweeps per pass only on levels with at least this many rows (536870912:
- *                          measured, four sweeps pay on 1025^3 rows, three on 513^3, pairs below)
+ *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep the pairs (16777216)
+ *     "fuse_k4_min_rows"   ... more than three sweeps per pass only on levels with at least this many rows (0)
  *     "fuse_k_small_tiles" 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than the GPU has CUs (0:
  *                          measured slower)
  *     "fuse_k_pf"          register sets for the planes of x that arrive: 2 = a second set keeps x staged one step longer

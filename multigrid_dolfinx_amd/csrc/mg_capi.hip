@@ -258,16 +258,17 @@ struct mg_context {
     int fuse_plain_shape = 0;       // ... its launch shape: 0 = 12 waves x 1 line (no spills), 1 = 8 x 2, 2 = 16 x 1
     int fuse_plain = 2;             // the pass on the stored rows (no classes): 2 = round-2 structure (sdia_jacobi2p), 1 = round 1's
     int class_sweeps = 1;           // so do the one-sweep kernels (residual, single Jacobi / Gauss-Seidel sweeps, SpMV)
-    int fuse_k = 4;                 // sweeps per pass of the class-coded K-sweep march (mg_jacobik3d.hip.h): 3..5; < 3: pairs only
-    int fuse_k_shape = 1;           // ... its tile: 0 = 128 x 24 cells (12 waves x 2 lines), 1 = 64 x 48 (12 waves x 4 lines; measured best),
-                                    // 2 = 128 x 24 (8 waves x 3 lines, 256 registers), 3 .. 5 = 64 x 24 by 6 / 8 / 4 waves, two workgroups per CU
+    int fuse_k = 5;                 // sweeps per pass of the class-coded K-sweep march (mg_jacobik3d.hip.h): 3..5; < 3: pairs only
+    int fuse_k_shape = 7;           // ... its tile: 0 = 128 x 24 cells (12 waves x 2 lines), 1 = 64 x 48 (12 waves x 4 lines),
+                                    // 2 = 128 x 24 (8 waves x 3 lines, 256 registers), 3 .. 5 = 64 x 24 by 6 / 8 / 4 waves, two workgroups
+                                    // per CU, 6 = 64 x 48 by 16 waves, 7 = 64 x 32 by 16 waves (no spills up to five sweeps: measured best)
     int fuse_k_segments = 0;        // ... plane segments per tile (0: chosen from the item count)
     int timing_force_form = -1;     // mg_time_kernel("jacobik3:formN"): every step of the K-sweep pass in one form (wrong results; how fast
                                     // each form is by itself)
     int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
     int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
-    int64_t fuse_k_min_rows = (int64_t)1 << 26;        // ... on whole levels with at least this many rows (fewer: pairs)
-    int64_t fuse_k4_min_rows = (int64_t)1 << 29;       // ... more than three sweeps per pass on levels with at least this many rows
+    int64_t fuse_k_min_rows = (int64_t)1 << 24;        // ... on whole levels with at least this many rows (fewer: pairs)
+    int64_t fuse_k4_min_rows = 0;                      // ... more than three sweeps per pass on levels with at least this many rows
     int fuse_k_small_tiles = 0;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
@@ -1274,8 +1275,8 @@ bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     return fused_sweeps_ok(c, L, ignore_size || slab) && L.g.nk >= 8;
 }
 
-// sweeps per pass on a whole level: measured on one MI355X (profiles/r03_ksweep_levels.txt), four pay on 1025^3 rows, three
-// on 513^3, pairs (mg_jacobi2.hip.h) below
+// sweeps per pass on a whole level (with the 64 x 32 tiles of 16 waves five sweeps per pass measured best on 1025^3, 513^3
+// and 257^3 rows alike, profiles/r03_ksweep_levels.txt; "fuse_k4_min_rows" caps smaller levels at three)
 int sweepsk_max(const mg_context* c, const Level& L) {
     return std::min(std::min(c->fuse_k, 5), L.nloc >= c->fuse_k4_min_rows ? 5 : 3);
 }
@@ -1340,6 +1341,8 @@ int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest, const JK3Ra
         case 3: return launch_jacobikc_t<K, 6, 4, 1, true, PF, 3, 64>(c, a, finest, zr, seglen);
         case 4: return launch_jacobikc_t<K, 8, 3, 1, true, PF, 4, 64>(c, a, finest, zr, seglen);
         case 5: if constexpr (K <= 4) return launch_jacobikc_t<K, 4, 6, 1, true, PF, 2, 64>(c, a, finest, zr, seglen);
+        case 6: if constexpr (K <= 4 && PF == 1) return launch_jacobikc_t<K, 16, 3, 1, true, 1, 4>(c, a, finest, zr, seglen);      // 64 x 48 by 16 waves
+        case 7: return launch_jacobikc_t<K, 16, 2, 1, true, PF, 4>(c, a, finest, zr, seglen);                                      // 64 x 32 by 16 waves
         default: return launch_jacobikc_t<K, 12, 2, 2, true, PF>(c, a, finest, zr, seglen);
     }
 }
@@ -1347,8 +1350,8 @@ int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest, const JK3Ra
 template <int K>
 int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest, const JK3Range& zr, int seglen) {
     // a second plane of x staged in registers ("fuse_k_pf" 2) fits the register budget with three sweeps only
-    if constexpr (K == 3) {
-        if (c->fuse_k_pf == 2) return launch_jacobikc_kp<K, 2>(c, a, finest, zr, seglen);
+    if constexpr (K == 3 || K == 4) {
+        if (c->fuse_k_pf == 2 && (K == 3 || c->fuse_k_shape == 7)) return launch_jacobikc_kp<K, 2>(c, a, finest, zr, seglen);
     }
     // (two sweeps per pass: slabs only, where a pass also saves an exchange; one tile shape)
     if constexpr (K == 2) return launch_jacobikc_t<K, 12, 4, 1, true, 1>(c, a, finest, zr, seglen);
@@ -2889,7 +2892,7 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         if (value < 0 || value > 5) return fail("fuse_k must be in 0..5 (below 3: pairs of sweeps only)");
         c->fuse_k = (int)value;
     } else if (k == "fuse_k_shape") {
-        if (value < 0 || value > 5) return fail("fuse_k_shape must be 0..5");
+        if (value < 0 || value > 7) return fail("fuse_k_shape must be 0..7");
         c->fuse_k_shape = (int)value;
     } else if (k == "fuse_k_slab_min_rows") {
         c->fuse_k_slab_min_rows = value;

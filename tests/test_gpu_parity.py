@@ -1217,7 +1217,8 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
                 dict(fuse_k=4, fuse_k_dpp=0), dict(fuse_k=3, fuse_k_dpp=0, fuse_k_segments=2),
                 dict(fuse_k=3, fuse_k_shape=3), dict(fuse_k=4, fuse_k_shape=3, fuse_k_segments=2), dict(fuse_k=5, fuse_k_shape=3),
                 dict(fuse_k=3, fuse_k_shape=4, fuse_k_segments=3), dict(fuse_k=4, fuse_k_shape=4), dict(fuse_k=4, fuse_k_shape=5),
-                dict(fuse_k=3, fuse_k_shape=1, fuse_k_pf=2), dict(fuse_k=3, fuse_k_shape=2, fuse_k_pf=2, fuse_k_segments=2)]
+                dict(fuse_k=3, fuse_k_shape=1, fuse_k_pf=2), dict(fuse_k=3, fuse_k_shape=2, fuse_k_pf=2, fuse_k_segments=2),
+                dict(fuse_k=3, fuse_k_shape=6), dict(fuse_k=4, fuse_k_shape=7, fuse_k_segments=2)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}

@@ -28,7 +28,7 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=50, mu2=50) as h:
         name = "jacobik3" + (":skip" + skip if skip else "") + (":form" + form if form else "!")
         ms = h.time_kernel(name, hi, reps)
         print(f"{spec:44s} {ms:8.3f} ms = {ms / k:6.3f} ms per sweep, {25 * n / ms / 1e6:7.1f} GB/s on 25 B/row", flush=True)
-        h.set_tuning("fuse_k_shape", 1)
+        h.set_tuning("fuse_k_shape", 7)
         h.set_tuning("fuse_k_segments", 0)
         h.set_tuning("fuse_k_dpp", 1)
         h.set_tuning("fuse_k_pf", 1)
