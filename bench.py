@@ -251,6 +251,9 @@ def build_hierarchy(args, rv):
     if args.transport == "gloo":            # ranks may share a GPU in this debugging mode
         import torch
         device = rv.local_rank % max(1, torch.cuda.device_count())
+    if rv.world > 1 and args.config != "c5":
+        # slabs: room for five halo planes, so that five sweeps share one grouped exchange (the K-sweep march on slabs)
+        tuning.setdefault("halo_depth", 5)
     if args.config == "c5":
         if rv.world > 1:
             tuning["halo_planes"] = 2           # P2 rows reach two lattice planes

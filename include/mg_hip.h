@@ -194,6 +194,11 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          summation order) then still get the compact formats.  This PERTURBS the matrix by up to k ulps
  *                          per entry -- below the round-off of the assembly itself for small k -- so results agree with the
  *                          exact-storage ones to ~k * 1e-16 relative, not bit for bit.  (0: everything bit for bit)
+ *     "storage_auto"       1 = a level whose exact symmetry test or row dictionary fails is tried once more with entries within
+ *                          2 units in the last place counting as equal (what an assembly with row-dependent round-off needs
+ *                          to reach the compact formats: 2.6 x on the headline pass); the perturbation -- at most 2 ulps per
+ *                          entry, below the assembly's own round-off -- is reported by mg_level_storage.  0 = exact storage
+ *                          only (1)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
  *     "halo_depth"         halo planes every vector of a slab has ROOM for, >= "halo_planes" (0 .. 5; 0: just those).  With K
  *                          planes of room the K-sweep march ("fuse_k") runs on slabs too: K planes of the iterate travel once per
@@ -286,6 +291,19 @@ int mg_level_info(mg_handle h, int level, int64_t* n_global, int64_t* n_local, i
  * carries one class byte per row (the row's five or seven entries, bit for bit, from a table), 0 when it does not
  * (more than 255 distinct rows, another format, "row_classes" 0).  No reference counterpart: storage detail of jacobiRelaxation (multigrid.py:223-228). */
 int mg_level_row_classes(mg_handle h, int level, int* classes);
+/* Why a level has the storage it has (what `A.getValuesCSR()`, Multigrid_prototype.py:95-96, really delivered):
+ *   symmetric             1 = every pair a_ij, a_ji agrees bit for bit, 2 = within `ulps_used` units in the last place (the
+ *                         upper half is kept), 0 = not symmetric (the level keeps both halves), -1 = not tested (pattern not
+ *                         symmetric, coarsest level, "symmetric_storage" 0)
+ *   first_asymmetric_row  lowest row (lexicographic grid numbering, local to the rank) with a pair that differs, -1 = none
+ *   max_pair_ulps         largest distance between the halves of a pair in units in the last place; -1 = a pair with one half
+ *                         missing or of the other sign
+ *   distinct_rows         distinct non-zero rows the row dictionary saw (more than 255: no row classes), -1 = not built
+ *   ulps_used             0 = the stored matrix is the handed-over one bit for bit; k > 0: entries within k units in the last
+ *                         place were identified ("storage_ulps", or the automatic second try "storage_auto" with k = 2)
+ * Any pointer may be null.  No reference counterpart: storage detail. */
+int mg_level_storage(mg_handle h, int level, int* symmetric, int64_t* first_asymmetric_row, int64_t* max_pair_ulps,
+                     int* distinct_rows, int* ulps_used);
 
 /* ---- vectors ---------------------------------------------------------------------------
  * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the

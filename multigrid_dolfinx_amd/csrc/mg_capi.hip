@@ -128,6 +128,11 @@ struct Level {
     int64_t n_global = 0, row0 = 0, nloc = 0, xlen = 0, halo_lo = 0, halo_hi = 0;
     bool replicated = true;      // false: this rank holds one slab and exchanges halos
     int hd = 0;                  // halo planes each vector of this level has room for (slabs)
+    // how the matrix got its storage (mg_level_storage): bit-for-bit symmetric / within 2^sym_qbits ulps / not; first
+    // asymmetric row (local lexicographic, -1: none) and the largest ulp distance of a pair; distinct rows seen by the class
+    // dictionary (-1: not built) and the tolerance it was built with
+    int rep_sym = -1, rep_sym_qbits = 0, rep_cls_qbits = 0, rep_distinct = -1;
+    int64_t rep_first_asym = -1, rep_max_ulps = 0;
     int cls_halo = 0;            // row classes of the neighbours' planes next to this slab: 0 not built yet, 1 in place, -1 unavailable
     bool flat = false;           // no grid structure (stand-alone smoother on any matrix)
     int W = 0, R = 1;
@@ -248,6 +253,7 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 2 ulps
     int storage_qbits = 0;          // "storage_ulps": low mantissa bits ignored by the symmetry test and the row dictionary
     int use_classes = 1;            // one class byte per row where a level has <= 255 distinct rows (two-sweep pass)
     int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
@@ -482,6 +488,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
     L.cls_halo = 0;
+    L.rep_sym = -1; L.rep_sym_qbits = L.rep_cls_qbits = 0; L.rep_distinct = -1; L.rep_first_asym = -1; L.rep_max_ulps = 0;
     dev_free(c, L.scls, (size_t)L.nslices * WAVE * L.R);
     dev_free(c, L.s_off, (size_t)256 * L.W);
     dev_free(c, L.s_val, (size_t)256 * L.W);
@@ -2274,8 +2281,18 @@ int encode_level(mg_context* c, Level& L) {
 
 // Row classes (mg_jacobi2.hip.h, "row classes"): a dictionary of the level's distinct FULL rows (five- or seven-point),
 // built and verified on the device; levels with more than 255 distinct non-zero rows go without.
+int build_row_classes_q(mg_context* c, Level& L, int qbits);
+
 int build_row_classes(mg_context* c, Level& L) {
     if (!c->use_classes || !L.sdia || (L.wu != 3 && L.wu != 4)) return 0;
+    MG_TRY(build_row_classes_q(c, L, c->storage_qbits));
+    // "storage_auto": rows that are almost repetitive (entries assembled with row-dependent round-off) get one more try
+    // in which entries within 2 units in the last place count as equal
+    if (!L.cls && c->storage_auto && c->storage_qbits == 0) MG_TRY(build_row_classes_q(c, L, 1));
+    return 0;
+}
+
+int build_row_classes_q(mg_context* c, Level& L, int qbits) {
     // scratch: hash tags | slot values | count, flag, slot_class[CLS_SLOTS], hist[256]
     struct Scratch {
         char* p = nullptr;
@@ -2300,7 +2317,7 @@ int build_row_classes(mg_context* c, Level& L) {
     a.svals = reinterpret_cast<double*>(scratch.p + tag_bytes);
     a.count = ints; a.flag = ints + 1; a.slot_class = ints + 2;
     a.hist = reinterpret_cast<unsigned*>(ints + 2 + CLS_SLOTS);
-    a.ctab = ctab; a.cls = cls; a.crows = cls_rows; a.clead = cls_lead; a.qbits = c->storage_qbits;
+    a.ctab = ctab; a.cls = cls; a.crows = cls_rows; a.clead = cls_lead; a.qbits = qbits;
     const dim3 grid(blocks_for(L.nloc, 256)), egrid(blocks_for(cls_rows, 256)), blk(256);
     int h[2] = {0, 0};
     std::vector<unsigned> hist(256, 0u);
@@ -2324,6 +2341,7 @@ int build_row_classes(mg_context* c, Level& L) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
     }();
+    if (!rc) { L.rep_distinct = h[0]; L.rep_cls_qbits = qbits; }
     if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass
         dev_free(c, cls, (size_t)cls_rows);
         dev_free(c, ctab, 256 * CLS_W);
@@ -2454,24 +2472,47 @@ int repack_sdia(mg_context* c, Level& L, int level) {
     double* dvals = nullptr;
     MG_TRY(dev_alloc(c, &dvals, (size_t)mslices * wu_t * S));
     a.dvals = dvals;
-    int* d_flag = nullptr;
+    int* d_flag = nullptr;              // flag | pad | report[2] (first asymmetric row + 1, largest ulp distance of a pair)
     int flag = 0;
+    unsigned long long report[2] = {~0ull, 0ull};
+    int qbits = c->storage_qbits;
     int rc = [&]() -> int {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flag), sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flag), 8 + 2 * sizeof(unsigned long long)));
+        unsigned long long* d_report = reinterpret_cast<unsigned long long*>(d_flag + 2);
         HIP_TRY(hipMemsetAsync(dvals, 0, (size_t)mslices * wu_t * S * sizeof(double), c->stream));
         const dim3 grid(blocks_for(L.nloc, 256)), blk(256);
         switch (L.R) {
-            case 1: hipLaunchKernelGGL(sdia_fill<1>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<1>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
-            case 2: hipLaunchKernelGGL(sdia_fill<2>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<2>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
-            default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); hipLaunchKernelGGL(sdia_check<4>, grid, blk, 0, c->stream, a, d_flag, c->storage_qbits); break;
+            case 1: hipLaunchKernelGGL(sdia_fill<1>, grid, blk, 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(sdia_fill<2>, grid, blk, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); break;
         }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            // ("storage_auto": pairs that differ by at most 2 units in the last place -- round-off of an assembly that sums its
+            //  element contributions in varying order -- get a second try with that tolerance; the upper half of a pair is kept)
+            HIP_TRY(hipMemsetAsync(d_flag, 0, 8, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_report, report, sizeof(report), hipMemcpyHostToDevice, c->stream));
+            switch (L.R) {
+                case 1: hipLaunchKernelGGL(sdia_check<1>, grid, blk, 0, c->stream, a, d_flag, qbits, d_report); break;
+                case 2: hipLaunchKernelGGL(sdia_check<2>, grid, blk, 0, c->stream, a, d_flag, qbits, d_report); break;
+                default: hipLaunchKernelGGL(sdia_check<4>, grid, blk, 0, c->stream, a, d_flag, qbits, d_report); break;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(report, d_report, sizeof(report), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!(flag && attempt == 0 && c->storage_auto && qbits == 0 && report[1] <= 2)) break;
+            qbits = 1;
+            report[0] = ~0ull; report[1] = 0ull;
+        }
         return 0;
     }();
     (void)hipFree(d_flag);
+    if (!rc) {
+        L.rep_first_asym = report[0] == ~0ull ? -1 : (int64_t)report[0] - 1;
+        L.rep_max_ulps = report[1] >= (1ull << 62) ? -1 : (int64_t)report[1];
+        L.rep_sym = flag ? 0 : (report[0] == ~0ull ? 1 : 2);
+        L.rep_sym_qbits = flag ? 0 : qbits;
+    }
     if (rc || flag) {                                           // not symmetric: keep the coded form
         dev_free(c, dvals, (size_t)mslices * wu_t * S);
         return rc;
@@ -2807,6 +2848,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         int q = 0;
         while ((1ll << q) < value) ++q;
         c->storage_qbits = value > 0 ? std::max(1, q) : 0;
+    } else if (k == "storage_auto") {
+        for (auto& L : c->L)
+            if (L.set) return fail("storage_auto must be chosen before level set-up");
+        c->storage_auto = value != 0;
     } else if (k == "row_classes") {
         for (auto& L : c->L)
             if (L.set) return fail("row_classes must be chosen before level set-up");
@@ -3276,6 +3321,18 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
     if (ell_width) *ell_width = L.W;
     if (replicated) *replicated = L.replicated ? 1 : 0;
     if (offset_codes) *offset_codes = L.sdia ? -L.wu : (L.coded ? L.ntable : 0);
+    return 0;
+}
+
+int mg_level_storage(mg_handle c, int level, int* symmetric, int64_t* first_asymmetric_row, int64_t* max_pair_ulps,
+                     int* distinct_rows, int* ulps_used) {
+    MG_TRY(check_level(c, level));
+    const Level& L = c->L[level];
+    if (symmetric) *symmetric = L.rep_sym;
+    if (first_asymmetric_row) *first_asymmetric_row = L.rep_first_asym;
+    if (max_pair_ulps) *max_pair_ulps = L.rep_max_ulps;
+    if (distinct_rows) *distinct_rows = L.rep_distinct;
+    if (ulps_used) *ulps_used = std::max(L.sdia ? (L.rep_sym_qbits ? 1 << L.rep_sym_qbits : 0) : 0, L.cls ? (L.rep_cls_qbits ? 1 << L.rep_cls_qbits : 0) : 0);
     return 0;
 }
 

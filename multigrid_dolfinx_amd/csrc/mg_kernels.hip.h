@@ -770,8 +770,11 @@ __global__ void sdia_fill(SdiaArgs a) {
 
 // Pass 2: every row's lower entries (absent = 0) must equal, bit for bit, what the symmetric kernel will
 // read for them; flag[0] |= 1 otherwise.
+// report (set-up diagnostics, mg_level_storage): report[0] = lowest row (+ 1) with a pair that is not bit-for-bit
+// symmetric, report[1] = largest distance between the halves of a pair in units in the last place (2^62: a pair with
+// one half absent or of the other sign)
 template <int R>
-__global__ void sdia_check(SdiaArgs a, int* flag, int qbits) {
+__global__ void sdia_check(SdiaArgs a, int* flag, int qbits, unsigned long long* report) {
     constexpr int S = WAVE * R;
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= a.nloc) return;
@@ -794,7 +797,13 @@ __global__ void sdia_check(SdiaArgs a, int* flag, int qbits) {
         // ("storage_ulps": the two halves of a pair may differ in their lowest qbits mantissa bits; the upper one is kept)
         const long long dw = __double_as_longlong(want) - __double_as_longlong(lower[c]);
         const bool close = qbits > 0 && (want < 0.0) == (lower[c] < 0.0) && (dw < 0 ? -dw : dw) <= (1ll << qbits);
-        if (__double_as_longlong(want) != __double_as_longlong(lower[c]) && !(want == 0.0 && lower[c] == 0.0) && !close) bad = true;
+        const bool differs = __double_as_longlong(want) != __double_as_longlong(lower[c]) && !(want == 0.0 && lower[c] == 0.0);
+        if (differs && !close) bad = true;
+        if (differs) {
+            const bool comparable = want != 0.0 && lower[c] != 0.0 && (want < 0.0) == (lower[c] < 0.0);
+            atomicMin(report, (unsigned long long)(row + 1));
+            atomicMax(report + 1, comparable ? (unsigned long long)(dw < 0 ? -dw : dw) : (1ull << 62));
+        }
     }
     if (bad) atomicOr(flag, 1);
 }

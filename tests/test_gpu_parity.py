@@ -1358,19 +1358,28 @@ def test_storage_ulps_brings_round_off_noisy_assemblies_to_the_compact_formats()
     n = A.shape[0]
     v_in = rng.standard_normal(n)
     outs = {}
-    for ulps in (0, 8):
-        with DeviceHierarchy(3, 1, 3, c=5, storage_ulps=ulps) as dev:
+    for ulps in (0, 8, "auto"):
+        # (0: exact storage only, the automatic second try off; "auto": the defaults -- a level whose exact symmetry test or
+        #  row dictionary fails by at most 2 ulps is taken with that tolerance, and says so in mg_level_storage)
+        kw = dict(storage_auto=0) if ulps == 0 else dict(storage_ulps=ulps) if ulps == 8 else {}
+        with DeviceHierarchy(3, 1, 3, c=5, **kw) as dev:
             dev.set_tuning("fuse_min_rows", 0)
             for l in (1, 2):
                 dev.set_level(l, bag.A_sp_dict[l][0], bag.levels[l].grid_index)
             dev.set_level(3, A, bag.levels[3].grid_index)
             dev.set_params(4, 4, 2.0 / 3.0)
             info = dev.level_info(3)
+            st = dev.level_storage(3)
             if ulps == 0:
                 assert info["symmetric_diagonals"] == 0 and info["offset_codes"] == 7 and info["row_classes"] == 0, info
+                # ... and why: the first row with a pair that is not symmetric bit for bit, by how many ulps at most
+                assert st["symmetric"] == 0 and st["first_asymmetric_row"] >= 0 and 1 <= st["max_pair_ulps"] <= 2 and st["ulps_used"] == 0, st
             else:
                 assert info["symmetric_diagonals"] == 4 and 2 <= info["row_classes"] <= 255, info
                 assert dev.time_kernel("jacobi2", 3, 1) > 0.0
+                assert st["symmetric"] == 2 and st["ulps_used"] == (8 if ulps == 8 else 2) and 2 <= st["distinct_rows"] <= 255, st
+            assert dev.level_storage(2) == dict(symmetric=1, first_asymmetric_row=-1, max_pair_ulps=0, ulps_used=0,
+                                                distinct_rows=dev.level_info(2)["row_classes"] - 1)
             dev.set_vector(3, "v", v_in)
             dev.set_vector(3, "f", bag.b_dict[3])
             dev.smooth(3, 6)
@@ -1378,9 +1387,10 @@ def test_storage_ulps_brings_round_off_noisy_assemblies_to_the_compact_formats()
             dev.zero_vector(3, "v")
             res = dev.vcycle(3, 3, residuals=True)
             outs[ulps] = (sm, res, dev.get_vector(3, "v"))
-    assert rel_l2(outs[8][0], outs[0][0]) <= 1e-13
-    assert np.all(np.abs(outs[8][1] - outs[0][1]) <= 1e-11 * outs[0][1])
-    assert rel_l2(outs[8][2], outs[0][2]) <= 1e-12
+    for k in (8, "auto"):
+        assert rel_l2(outs[k][0], outs[0][0]) <= 1e-13
+        assert np.all(np.abs(outs[k][1] - outs[0][1]) <= 1e-11 * outs[0][1])
+        assert rel_l2(outs[k][2], outs[0][2]) <= 1e-12
 
 
 def test_time_kernel_reports_where_the_two_sweep_pass_is_not_used():

@@ -10,7 +10,7 @@ LOG=$OUT/${TAG}_final.log
 cd "$R"
 make -C tests/fake_rccl > /dev/null 2>&1
 echo "== pytest" > "$LOG"
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > "$OUT/${TAG}_gpu_tests.log" 2>&1; echo "pytest rc=$?" >> "$LOG"; tail -3 "$OUT/${TAG}_gpu_tests.log" >> "$LOG"
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$OUT/${TAG}_gpu_tests.log" 2>&1; echo "pytest rc=$?" >> "$LOG"; tail -3 "$OUT/${TAG}_gpu_tests.log" >> "$LOG"
 echo "== profile" >> "$LOG"
 timeout -k 10 600 bash tools/profile_round.sh "$TAG" >> "$LOG" 2>&1
 for c in c1 c2 c3 c5; do
@@ -24,8 +24,8 @@ timeout -k 10 200 python tools/slab_overhead_probe.py 2 7 50 > "$OUT/${TAG}_slab
 echo "== one slab of eight alone (loopback stand-in)" >> "$LOG"
 export MG_RCCL_LIBRARY=$R/tests/fake_rccl/libfake_rccl_loopback.so
 for mu in 50 2; do
-  for t in graph_comm=0 graph_comm=1; do
-    timeout -k 10 300 python tools/slab_rank_probe.py 8 7 $mu $t >> "$OUT/${TAG}_slab_rank.txt" 2>&1; tail -1 "$OUT/${TAG}_slab_rank.txt" >> "$LOG"
+  for t in "" halo_depth=5 halo_depth=5,overlap=0; do
+    timeout -k 10 300 python tools/slab_rank_probe.py 8 7 $mu "$t" >> "$OUT/${TAG}_slab_rank.txt" 2>&1; tail -1 "$OUT/${TAG}_slab_rank.txt" >> "$LOG"
   done
 done
 echo "== done" >> "$LOG"

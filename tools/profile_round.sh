@@ -4,7 +4,7 @@
 # 1. kernel trace + stats of the default bench run (the headline workload),
 # 2. separate PMC passes (FETCH_SIZE, WRITE_SIZE, L2 hit/miss) of a short bench run -- counters never share a run
 #    with --stats or another trace domain --,
-# 3. SQ wait / busy counters of the pair pass alone (tools/pmc_jacobi2.py),
+# 3. SQ wait / busy / instruction counters of the K-sweep pass alone (tools/pmc_ksweep.py),
 # each condensed with profiles/summarize.py into gpurun_out/${TAG}_*.csv (copy those into profiles/).
 # rocprofv3 must launch python3 itself (no env/bash wrapper between it and the program).
 set -e
@@ -32,8 +32,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c5_pmc_$N.d" "$OUT/${TAG}_c5_pmc_$N.csv"
 done
 echo "sq"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq.d" -- python3 "$R/tools/pmc_jacobi2.py" > "$OUT/${TAG}_c4_pmc_sq.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq.d" -- python3 "$R/tools/pmc_ksweep.py" > "$OUT/${TAG}_c4_pmc_sq.log" 2>&1
 python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq.d" "$OUT/${TAG}_c4_pmc_sq.csv"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq2.d" -- python3 "$R/tools/pmc_ksweep.py" > "$OUT/${TAG}_c4_pmc_sq2.log" 2>&1
+python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq2.d" "$OUT/${TAG}_c4_pmc_sq2.csv"
 cd "$R"
 echo "plain"; python3 bench.py > "$OUT/${TAG}_c4_bench_untraced.json" 2> "$OUT/${TAG}_c4_untraced.err"
 rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d "$OUT"/${TAG}_c5_pmc_*.d
