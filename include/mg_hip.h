@@ -195,8 +195,8 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          per entry -- below the round-off of the assembly itself for small k -- so results agree with the
  *                          exact-storage ones to ~k * 1e-16 relative, not bit for bit.  (0: everything bit for bit)
  *     "storage_auto"       1 = a level whose exact symmetry test or row dictionary fails is tried once more with entries within
- *                          2 units in the last place counting as equal (what an assembly with row-dependent round-off needs
- *                          to reach the compact formats: 2.6 x on the headline pass); the perturbation -- at most 2 ulps per
+ *                          4 units in the last place counting as equal (what an assembly with row-dependent round-off needs
+ *                          to reach the compact formats: 2.6 x on the headline pass); the perturbation -- at most 4 ulps per
  *                          entry, below the assembly's own round-off -- is reported by mg_level_storage.  0 = exact storage
  *                          only (1)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
@@ -300,7 +300,7 @@ int mg_level_row_classes(mg_handle h, int level, int* classes);
  *                         missing or of the other sign
  *   distinct_rows         distinct non-zero rows the row dictionary saw (more than 255: no row classes), -1 = not built
  *   ulps_used             0 = the stored matrix is the handed-over one bit for bit; k > 0: entries within k units in the last
- *                         place were identified ("storage_ulps", or the automatic second try "storage_auto" with k = 2)
+ *                         place were identified ("storage_ulps", or the automatic second try "storage_auto" with k = 4)
  * Any pointer may be null.  No reference counterpart: storage detail. */
 int mg_level_storage(mg_handle h, int level, int* symmetric, int64_t* first_asymmetric_row, int64_t* max_pair_ulps,
                      int* distinct_rows, int* ulps_used);

@@ -253,7 +253,7 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
-    int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 2 ulps
+    int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 4 ulps
     int storage_qbits = 0;          // "storage_ulps": low mantissa bits ignored by the symmetry test and the row dictionary
     int use_classes = 1;            // one class byte per row where a level has <= 255 distinct rows (two-sweep pass)
     int fuse_sweeps = 1;            // pairs of Jacobi sweeps in one pass (mg_jacobi2.hip.h) on large 3-D levels
@@ -2287,8 +2287,8 @@ int build_row_classes(mg_context* c, Level& L) {
     if (!c->use_classes || !L.sdia || (L.wu != 3 && L.wu != 4)) return 0;
     MG_TRY(build_row_classes_q(c, L, c->storage_qbits));
     // "storage_auto": rows that are almost repetitive (entries assembled with row-dependent round-off) get one more try
-    // in which entries within 2 units in the last place count as equal
-    if (!L.cls && c->storage_auto && c->storage_qbits == 0) MG_TRY(build_row_classes_q(c, L, 1));
+    // in which entries within 4 units in the last place (2^-50 relative: one ulp either way, across a power of two) count as equal
+    if (!L.cls && c->storage_auto && c->storage_qbits == 0) MG_TRY(build_row_classes_q(c, L, 2));
     return 0;
 }
 
@@ -2487,7 +2487,7 @@ int repack_sdia(mg_context* c, Level& L, int level) {
             default: hipLaunchKernelGGL(sdia_fill<4>, grid, blk, 0, c->stream, a); break;
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
-            // ("storage_auto": pairs that differ by at most 2 units in the last place -- round-off of an assembly that sums its
+            // ("storage_auto": pairs that differ by at most 4 units in the last place -- round-off of an assembly that sums its
             //  element contributions in varying order -- get a second try with that tolerance; the upper half of a pair is kept)
             HIP_TRY(hipMemsetAsync(d_flag, 0, 8, c->stream));
             HIP_TRY(hipMemcpyAsync(d_report, report, sizeof(report), hipMemcpyHostToDevice, c->stream));
@@ -2500,8 +2500,8 @@ int repack_sdia(mg_context* c, Level& L, int level) {
             HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(report, d_report, sizeof(report), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (!(flag && attempt == 0 && c->storage_auto && qbits == 0 && report[1] <= 2)) break;
-            qbits = 1;
+            if (!(flag && attempt == 0 && c->storage_auto && qbits == 0 && report[1] <= 4)) break;
+            qbits = 2;
             report[0] = ~0ull; report[1] = 0ull;
         }
         return 0;
