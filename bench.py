@@ -257,10 +257,10 @@ def build_hierarchy(args, rv):
     if args.config == "c5":
         if rv.world > 1:
             tuning["halo_planes"] = 2           # P2 rows reach two lattice planes
-        # transfers: the P2 prolongation and (single GPU: it reaches three fine planes) its transpose as restriction
+            tuning.setdefault("halo_depth", 3)  # ... and the transpose of the P2 prolongation three fine planes
+        # transfers: the P2 prolongation and its transpose as restriction (the same algorithm on one GPU and on slabs)
         return DeviceHierarchy.synthetic_p2(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega, device=device,
-                                            comm=comm, transfers="p2", restriction="table" if rv.world == 1 else "direct",
-                                            **tuning)
+                                            comm=comm, transfers="p2", restriction="table", **tuning)
     return DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega,
                                      prune_zeros=True, device=device, comm=comm, **tuning)
 
@@ -500,7 +500,7 @@ def main():
 
     # conventional V(2,2) for information
     h.set_params(2, 2, args.omega, smoother="mcgs" if p2 else "jacobi",
-                 restriction="table" if (p2 and rv.world == 1) else "direct")
+                 restriction="table" if p2 else "direct")
     v22 = timed_cycles(h, rv, hi, 1, max(2, args.steps))
     v22_per_s = max(2, args.steps) / v22
     mem = h.memory_bytes()
@@ -516,7 +516,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) omega={args.omega:.4f}, "
-                                   f"P2 prolongation and its transpose as restriction (injection on slabs), exact block-LU coarsest solve, up to 51 "
+                                   f"P2 prolongation and its transpose as restriction, exact block-LU coarsest solve, up to 51 "
                                    f"entries per row; "
                                    f"no reference implementation exists for this configuration (parity unpinned)" if p2 else
                                    f"{desc}, {(8 * 2 ** hi + 1) ** dim} DoF, V({args.mu},{args.mu}) weighted Jacobi "

@@ -1798,7 +1798,11 @@ int restrict_to(mg_context* c, int level, int kind) {
     Grid gc = coarse_target_grid(c, C, F);
     if (kind == MG_RESTRICT_TABLE) {
         if (!c->rtab_count) return fail("no restriction table (mg_set_restriction_table)");
-        if (!F.replicated && c->comm.active()) return fail("the table restriction reaches three fine planes: whole levels only");
+        // (the transpose of the P2 prolongation reaches three fine planes: on slabs the residual's halo must have room for them)
+        if (!F.replicated && c->comm.active()) {
+            if (F.hd < 3) return fail("the table restriction reaches three fine planes: \"halo_depth\" must be at least 3 on slabs");
+            MG_TRY(exchange_halo(c, F, F.v2, nullptr, 3));
+        }
         const RestrictTable t{c->rtab_count, c->rtab_off, c->rtab_w, c->rtab_m};
         hipLaunchKernelGGL(restrict_table, grid3(gc, gc.nk), dim3(kPlaneBlock), 0, c->stream, gc, F.g, t, F.v2.base, C.f.base);
     } else if (kind == MG_RESTRICT_FULL_WEIGHTING) {

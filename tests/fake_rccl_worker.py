@@ -122,10 +122,13 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
     results, errors = [None] * world, []
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("MG_TEST_TUNE", "").split(",") if kv}
 
+    table = bool(os.environ.get("MG_TEST_P2_TABLE"))        # the P2 prolongation and its transpose (three fine planes of reach)
+    extra = dict(transfers="p2", restriction="table") if table else {}
+
     def run(h):
         out = []
         for sm, om in (("mcgs", 1.0), ("jacobi", 0.6)):
-            h.set_params(mu, mu, om, smoother=sm)
+            h.set_params(mu, mu, om, smoother=sm, restriction="table" if table else "direct")
             h.zero_vector(hi, "v")
             out.append(np.asarray(h.vcycle(hi, 2, residuals=True)))
             out.append(h.get_vector(hi, "v", gather=True))
@@ -138,7 +141,7 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
                 h.set_tuning("overlap", overlap)
                 h.set_tuning("overlap_min_rows", 0)
                 h.set_comm_rccl(rank, world, uid, replicate_below=replicate_below)
-            h = DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, halo_planes=2, **tune)
+            h = DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, comm=comm, halo_planes=2, **extra, **tune)
             info = h.level_info(hi)
             assert not info["replicated"] and info["n_local"] < info["n_global"]
             results[rank] = run(h)
@@ -155,7 +158,7 @@ def main_p2(world, dim, lo, hi, c, mu, replicate_below, overlap):
         t.join(timeout=240)
     assert not any(t.is_alive() for t in threads), "a rank is stuck: the exchange pattern deadlocked"
     assert not errors, errors
-    with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, **tune) as ser:
+    with DeviceHierarchy.synthetic_p2(dim, lo, hi, c=c, mu1=mu, mu2=mu, **extra, **tune) as ser:
         want = run(ser)
     for rank in range(world):
         got = results[rank]

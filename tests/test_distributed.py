@@ -130,7 +130,9 @@ def test_slab_cycles_captured_into_graphs_with_their_exchanges(world, dim, lo, h
 @pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap,tune", [
     (2, 3, 1, 3, 4, 0, 1, ""), (3, 3, 1, 3, 4, 0, 0, ""), (2, 2, 1, 4, 8, 0, 1, ""), (4, 3, 1, 3, 4, 2000, 1, ""),
     (2, 3, 1, 3, 4, 0, 1, "lattice_march_min_rows=0"), (3, 3, 1, 3, 8, 0, 0, "lattice_march_min_rows=0"),
-    (4, 3, 1, 3, 8, 2000, 1, "lattice_march_min_rows=0,lattice_segments=2")])
+    (4, 3, 1, 3, 8, 2000, 1, "lattice_march_min_rows=0,lattice_segments=2"),
+    (2, 3, 1, 3, 4, 0, 1, "halo_depth=3,table=1"), (3, 3, 1, 3, 8, 0, 0, "halo_depth=3,table=1,lattice_march_min_rows=0"),
+    (2, 2, 1, 4, 8, 0, 1, "halo_depth=3,table=1")])
 def test_p2_levels_on_slabs_with_two_plane_halos(world, dim, lo, hi, c, rep, overlap, tune):
     """BASELINE config 5 distributed: P2 rows reach two lattice planes, so the slabs exchange two planes per neighbour
     (`halo_planes` = 2).  Nine-colour Gauss-Seidel (a halo refresh after every colour) and weighted-Jacobi cycles on
@@ -144,7 +146,9 @@ def test_p2_levels_on_slabs_with_two_plane_halos(world, dim, lo, hi, c, rep, ove
     lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(lib):
         subprocess.run(["make", "-C", os.path.join(here, "fake_rccl")], check=True)
-    env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_P2="1", MG_TEST_TUNE=tune)
+    env = dict(os.environ, MG_RCCL_LIBRARY=lib, MG_TEST_P2="1", MG_TEST_TUNE=",".join(kv for kv in tune.split(",") if kv != "table=1"))
+    if "table=1" in tune:       # BASELINE config 5's own transfer pair on slabs: the restriction reaches three fine planes (halo_depth 3)
+        env["MG_TEST_P2_TABLE"] = "1"
     out = subprocess.run([sys.executable, os.path.join(here, "fake_rccl_worker.py"), str(world), str(dim), str(lo),
                           str(hi), str(c), "2", str(rep), str(overlap)], env=env, capture_output=True, text=True,
                          timeout=600)
