@@ -275,6 +275,7 @@ struct mg_context {
     int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
     int64_t fuse_k_min_rows = (int64_t)1 << 24;        // ... on whole levels with at least this many rows (fewer: pairs)
     int64_t fuse_k4_min_rows = 0;                      // ... more than three sweeps per pass on levels with at least this many rows
+    int fuse_k_tail = 1;            // ... the tiles left over for a last, nearly empty round of workgroups get shorter plane segments
     int fuse_k_small_tiles = 0;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
     int fuse_k_dpp = 1;             // ... -1 / +1 neighbours from the neighbouring lanes' registers (0: through LDS, tile 0 only)
@@ -1302,22 +1303,40 @@ int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest, const JK3Range& zr,
     a.za0 = zr.za0; a.za1 = zr.za1; a.zb0 = zr.zb0; a.zb1 = zr.zb1;
     const int planes = std::max(0, zr.za1 - zr.za0) + std::max(0, zr.zb1 - zr.zb0);
     if (planes <= 0) return 0;
+    a.ta = (int)ntile; a.seglen_b = 1;
+    int64_t items = 0;
     if (seglen <= 0) {
-        // plane segments: rounds of the resident workgroups (by LDS and by waves per SIMD), each item paying 2K steps of
-        // warm-up (which do about two thirds of a step's work)
-        const int64_t cus = std::max(1, c->prop.multiProcessorCount) * (int64_t)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(4 * WPE / NW)));
-        int best = 1;
+        // Plane segments.  The items run in rounds of the resident workgroups (by LDS and by waves per SIMD), each paying 2K
+        // steps of warm-up (which do about two thirds of a step's work).  A last round that only a few tiles are left for
+        // would keep most CUs idle for a whole segment: those tiles -- fewer than there are CUs -- are cut into as many shorter
+        // segments as fill the round once, and come last ("fuse_k_tail" 0: every tile alike).
+        int64_t cus = std::max(1, c->prop.multiProcessorCount) * (int64_t)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(4 * WPE / NW)));
+        if (c->fuse_k_tail > 1) cus = c->fuse_k_tail;       // (tests: a tail on grids of a few tiles)
+        const double warm = 1.4 * K;
+        int best = 1, best_ta = (int)ntile, best_m = 1;
         double best_cost = 1e300;
+        const bool tail = c->fuse_k_tail && zr.zb1 <= zr.zb0;
         for (int n = 1; n <= std::max(1, planes / 8); ++n) {
-            const double cost = (double)((ntile * n + cus - 1) / cus) * ((planes + n - 1) / n + 1.4 * K);
-            if (cost < best_cost) { best_cost = cost; best = n; }
+            const int len = (planes + n - 1) / n;
+            const int64_t full = ntile * n / cus;
+            int64_t ta = tail ? std::min<int64_t>(ntile, full * cus / n) : ntile;
+            if (ta <= 0 || (ntile - ta) * 2 > cus) ta = ntile;           // (a tail of more than half a round is a round)
+            const int64_t tb = ntile - ta;
+            const int m = tb > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(cus / tb, planes / 4)) : 1;
+            const double cost = (double)((ta * n + cus - 1) / cus) * (len + warm) + (tb > 0 ? (planes + m - 1) / m + warm : 0.0);
+            if (cost < best_cost) { best_cost = cost; best = n; best_ta = (int)ta; best_m = m; }
         }
-        if (c->fuse_k_segments > 0) best = std::min(c->fuse_k_segments, planes);
+        if (c->fuse_k_segments > 0) { best = std::min(c->fuse_k_segments, planes); best_ta = (int)ntile; }
         seglen = (planes + best - 1) / best;
+        a.ta = best_ta;
+        a.seglen_b = best_ta < ntile ? (planes + best_m - 1) / best_m : 1;
     }
     a.seglen = seglen;
-    const int nseg = (std::max(0, zr.za1 - zr.za0) + seglen - 1) / seglen + (std::max(0, zr.zb1 - zr.zb0) + seglen - 1) / seglen;
-    const int64_t items = ntile * nseg;
+    {
+        const int nseg = (std::max(0, zr.za1 - zr.za0) + seglen - 1) / seglen + (std::max(0, zr.zb1 - zr.zb0) + seglen - 1) / seglen;
+        items = (int64_t)a.ta * nseg;
+        if (a.ta < ntile) items += (ntile - a.ta) * (int64_t)((planes + a.seglen_b - 1) / a.seglen_b);
+    }
     if (items >= ((int64_t)1 << 31) - 4096) return fail("too many tiles");
     a.nitems = (unsigned)items;
     a.xcd_chunk = (unsigned)c->fuse_xcd_chunk;
@@ -2952,6 +2971,9 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_k_min_rows = value;
     } else if (k == "fuse_k4_min_rows") {
         c->fuse_k4_min_rows = value;
+    } else if (k == "fuse_k_tail") {
+        if (value < 0) return fail("fuse_k_tail must be >= 0");
+        c->fuse_k_tail = (int)value;            // (> 1: the number of resident workgroups to plan for -- tests)
     } else if (k == "fuse_k_small_tiles") {
         c->fuse_k_small_tiles = value != 0;
     } else if (k == "fuse_k_pf") {

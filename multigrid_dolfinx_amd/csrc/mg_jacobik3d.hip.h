@@ -58,6 +58,9 @@ struct JK3Args {
     // work items: tiles x plane segments of `seglen` planes; the launch covers the planes [za0, za1) and then [zb0, zb1)
     // (slabs: the planes the neighbours wait for in one launch, the rest in another; whole levels: [0, nz) and nothing)
     int ntx, nty, seglen, za0, za1, zb0, zb1;
+    // ... and so that the last round of workgroups is not a nearly empty one, the tiles from `ta` on (fewer than there are
+    // CUs; plane range a only) are cut into shorter segments of `seglen_b` planes and come last
+    int ta, seglen_b;
     unsigned nitems, xcd_chunk;
     int force_form;             // -1; timing experiments (mg_time_kernel only, results are wrong): every step in form 0 / 1 / 2
 };
@@ -99,12 +102,23 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     }
     if (id >= a.nitems) return;
     const unsigned ntile = (unsigned)(a.ntx * a.nty);
-    const int seg = (int)(id / ntile);
-    const unsigned tt = id % ntile;
-    const int tiy = (int)(tt / (unsigned)a.ntx), tix = (int)(tt % (unsigned)a.ntx);
     const int nsa = (a.za1 - a.za0 + a.seglen - 1) / a.seglen;
-    const int z0 = seg < nsa ? a.za0 + seg * a.seglen : a.zb0 + (seg - nsa) * a.seglen;
-    const int z1 = min(seg < nsa ? a.za1 : a.zb1, z0 + a.seglen);
+    const int nsb = (a.zb1 - a.zb0 + a.seglen - 1) / a.seglen;
+    const unsigned items_a = (unsigned)a.ta * (unsigned)(nsa + max(nsb, 0));
+    unsigned tt;
+    int z0, z1;
+    if (id < items_a) {
+        const int seg = (int)(id / (unsigned)a.ta);
+        tt = id % (unsigned)a.ta;
+        z0 = seg < nsa ? a.za0 + seg * a.seglen : a.zb0 + (seg - nsa) * a.seglen;
+        z1 = min(seg < nsa ? a.za1 : a.zb1, z0 + a.seglen);
+    } else {
+        const unsigned j = id - items_a, tb = ntile - (unsigned)a.ta;
+        tt = (unsigned)a.ta + j % tb;
+        z0 = a.za0 + (int)(j / tb) * a.seglen_b;
+        z1 = min(a.za1, z0 + a.seglen_b);
+    }
+    const int tiy = (int)(tt / (unsigned)a.ntx), tix = (int)(tt % (unsigned)a.ntx);
     if (z1 <= z0) return;
     const int tx0 = tix * WI - K, ty0 = tiy * HY - (K - 1);   // grid position of cell (0, 0)
 

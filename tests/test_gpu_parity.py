@@ -1230,7 +1230,11 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
                 dict(fuse_k=3, fuse_k_shape=3), dict(fuse_k=4, fuse_k_shape=3, fuse_k_segments=2), dict(fuse_k=5, fuse_k_shape=3),
                 dict(fuse_k=3, fuse_k_shape=4, fuse_k_segments=3), dict(fuse_k=4, fuse_k_shape=4), dict(fuse_k=4, fuse_k_shape=5),
                 dict(fuse_k=3, fuse_k_shape=1, fuse_k_pf=2), dict(fuse_k=3, fuse_k_shape=2, fuse_k_pf=2, fuse_k_segments=2),
-                dict(fuse_k=3, fuse_k_shape=6), dict(fuse_k=4, fuse_k_shape=7, fuse_k_segments=2)]
+                dict(fuse_k=3, fuse_k_shape=6), dict(fuse_k=4, fuse_k_shape=7, fuse_k_segments=2),
+                # (the tiles of a last, nearly empty round in shorter segments: planned for 4 / 5 / 7 resident workgroups so
+                #  that these few-tile grids have such a tail; 0: every tile alike)
+                dict(fuse_k=5, fuse_k_tail=4), dict(fuse_k=4, fuse_k_tail=5, fuse_k_shape=1), dict(fuse_k=3, fuse_k_tail=7),
+                dict(fuse_k=5, fuse_k_tail=0)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
