@@ -236,6 +236,9 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_k_slab_min_sweeps"  ... and smoother calls of at least this many sweeps (4)
  *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep the pairs (16777216)
  *     "fuse_k4_min_rows"   ... more than three sweeps per pass only on levels with at least this many rows (0)
+ *     "fuse_k5_min_rows"   ... more than four only on levels with at least this many rows (67108864: on 257^3 rows four
+ *                          sweeps per pass measured best)
+ *     "fuse_k_nt_store"    non-temporal stores of that march's result (experiment) (0)
  *     "fuse_k_tail"        the tiles left over for a last, nearly empty round of workgroups (fewer tiles than half the CUs) are cut
  *                          into shorter plane segments that fill that round once (1); bit-identical
  *     "fuse_k_small_tiles" 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than the GPU has CUs (0:

@@ -274,7 +274,9 @@ struct mg_context {
     int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
     int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
     int64_t fuse_k_min_rows = (int64_t)1 << 24;        // ... on whole levels with at least this many rows (fewer: pairs)
+    int64_t fuse_k5_min_rows = (int64_t)1 << 26;       // ... five sweeps per pass on levels with at least this many rows (257^3: four measured best)
     int64_t fuse_k4_min_rows = 0;                      // ... more than three sweeps per pass on levels with at least this many rows
+    int fuse_k_nt_store = 0;        // ... non-temporal stores of its result (experiment)
     int fuse_k_tail = 1;            // ... the tiles left over for a last, nearly empty round of workgroups get shorter plane segments
     int fuse_k_small_tiles = 0;     // ... 64 x 24 tiles (shape 4) on levels whose planes hold fewer 64 x 48 tiles than there are CUs
     int fuse_k_pf = 1;              // ... register sets for the planes of x that arrive (2: x staged a step longer, K = 3 only; measured no faster)
@@ -1283,10 +1285,10 @@ bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     return fused_sweeps_ok(c, L, ignore_size || slab) && L.g.nk >= 8;
 }
 
-// sweeps per pass on a whole level (with the 64 x 32 tiles of 16 waves five sweeps per pass measured best on 1025^3, 513^3
-// and 257^3 rows alike, profiles/r03_ksweep_levels.txt; "fuse_k4_min_rows" caps smaller levels at three)
+// sweeps per pass on a whole level (with the 64 x 32 tiles of 16 waves five sweeps per pass measured best on 1025^3 and 513^3
+// rows, four on 257^3, profiles/r03_ksweep_levels.txt; "fuse_k4_min_rows" caps smaller levels at three)
 int sweepsk_max(const mg_context* c, const Level& L) {
-    return std::min(std::min(c->fuse_k, 5), L.nloc >= c->fuse_k4_min_rows ? 5 : 3);
+    return std::min(std::min(c->fuse_k, 5), L.nloc < c->fuse_k4_min_rows ? 3 : L.nloc < c->fuse_k5_min_rows ? 4 : 5);
 }
 
 // plane ranges of one launch of the march: [za0, za1) and then [zb0, zb1)
@@ -1398,6 +1400,7 @@ int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, 
     a.phi = dist && c->comm.rank + 1 < c->comm.world ? K : 0;
     if (dist && (L.hd < K || L.cls_halo != 1)) return fail("the level's halos are not prepared for that many sweeps per pass");
     a.force_form = c->timing_force_form;
+    a.nt_store = c->fuse_k_nt_store;
     const JK3Range whole{0, L.g.nk, 0, 0};
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     switch (K) {
@@ -2969,8 +2972,12 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_k_slab_min_sweeps = (int)value;
     } else if (k == "fuse_k_min_rows") {
         c->fuse_k_min_rows = value;
+    } else if (k == "fuse_k5_min_rows") {
+        c->fuse_k5_min_rows = value;
     } else if (k == "fuse_k4_min_rows") {
         c->fuse_k4_min_rows = value;
+    } else if (k == "fuse_k_nt_store") {
+        c->fuse_k_nt_store = value != 0;
     } else if (k == "fuse_k_tail") {
         if (value < 0) return fail("fuse_k_tail must be >= 0");
         c->fuse_k_tail = (int)value;            // (> 1: the number of resident workgroups to plan for -- tests)

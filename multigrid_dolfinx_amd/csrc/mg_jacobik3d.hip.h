@@ -62,6 +62,7 @@ struct JK3Args {
     // CUs; plane range a only) are cut into shorter segments of `seglen_b` planes and come last
     int ta, seglen_b;
     unsigned nitems, xcd_chunk;
+    int nt_store;               // 1: non-temporal stores of the result
     int force_form;             // -1; timing experiments (mg_time_kernel only, results are wrong): every step in form 0 / 1 / 2
 };
 
@@ -265,7 +266,9 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     auto store = [&](int c, double v) {
         unsigned e8 = eo[c];
         asm volatile("" : "+v"(e8));
-        *(__attribute__((address_space(1))) double*)(k_out + e8) = v;
+        // (the result is next read a whole pass later: stored past the caches, it leaves the L2 to the tile rims)
+        if (a.nt_store) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) double*)(k_out + e8));
+        else *(__attribute__((address_space(1))) double*)(k_out + e8) = v;
     };
     // plane range of level t (rows outside it are zeros)
     int lo_t[K + 1], n_t[K + 1];

@@ -652,7 +652,7 @@ def _n128_oracle():
     return _N128["want"], _N128["res"]
 
 
-_SMALL = dict(fuse_min_rows=0, march_min_rows=0, fuse_k_min_rows=0, fuse_k4_min_rows=0)
+_SMALL = dict(fuse_min_rows=0, march_min_rows=0, fuse_k_min_rows=0, fuse_k4_min_rows=0, fuse_k5_min_rows=0)
 
 
 @pytest.mark.parametrize("tuning", [dict(), dict(_SMALL), dict(_SMALL, fuse_k=0), dict(_SMALL, fuse_k=3, fuse_k_shape=0),
@@ -1240,7 +1240,7 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
         classes = make.get("row_classes", 1)
         with DeviceHierarchy.synthetic(3, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
-            for key in ("fuse_min_rows", "fuse_k_min_rows", "fuse_k4_min_rows"):       # small grids: still the march kernels
+            for key in ("fuse_min_rows", "fuse_k_min_rows", "fuse_k4_min_rows", "fuse_k5_min_rows"):       # small grids: still the march kernels
                 dev.set_tuning(key, 0)
             for k, v in tune.items():
                 dev.set_tuning(k, v)
