@@ -199,6 +199,15 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          to reach the compact formats: 2.6 x on the headline pass); the perturbation -- at most 4 ulps per
  *                          entry, below the assembly's own round-off -- is reported by mg_level_storage.  0 = exact storage
  *                          only (1)
+ *     "gen_odd_rows"       mg_gen_poisson_level gives this many of 10000 interior rows, picked by a hash of their grid index, a
+ *                          reaction term of their own on the diagonal (a.diag * (1 + r), 0 <= r < 1): rows unlike any other,
+ *                          for measuring what "row_escape" costs.  Levels generated afterwards (0)
+ *     "row_escape"         1 = a symmetric seven-point level with more than 255 distinct rows keeps row classes when at least three
+ *                          quarters of its rows are copies of the 254 most frequent ones: the other rows ("escape rows":
+ *                          another material, a perturbed coefficient) are read from the stored matrix by the K-sweep march
+ *                          ("fuse_k"), which is then the only kernel that uses the classes -- same arithmetic, same results bit
+ *                          for bit.  Needs whole levels (not slabs) and no 64 x 32 tile of the march with more than 1024 such rows in
+ *                          K + 2 planes (512 for K = 5; the march takes the most sweeps per pass that fit); else, and with 0, such a level has no row classes.  Before level set-up (1)
  *     "row_classes"        0 skips the dictionary of distinct rows on symmetric 5- and 7-point levels (1)
  *     "halo_depth"         halo planes every vector of a slab has ROOM for, >= "halo_planes" (0 .. 5; 0: just those).  With K
  *                          planes of room the K-sweep march ("fuse_k") runs on slabs too: K planes of the iterate travel once per
@@ -306,9 +315,12 @@ int mg_level_row_classes(mg_handle h, int level, int* classes);
  *   distinct_rows         distinct non-zero rows the row dictionary saw (more than 255: no row classes), -1 = not built
  *   ulps_used             0 = the stored matrix is the handed-over one bit for bit; k > 0: entries within k units in the last
  *                         place were identified ("storage_ulps", or the automatic second try "storage_auto" with k = 4)
+ *   escape_rows           rows that have no class of their own although the level has row classes: the level had more than 255
+ *                         distinct rows, the 254 most frequent ones became classes and these rows are read from the stored
+ *                         matrix ("row_escape"); 0 = none
  * Any pointer may be null.  No reference counterpart: storage detail. */
 int mg_level_storage(mg_handle h, int level, int* symmetric, int64_t* first_asymmetric_row, int64_t* max_pair_ulps,
-                     int* distinct_rows, int* ulps_used);
+                     int* distinct_rows, int* ulps_used, int64_t* escape_rows);
 
 /* ---- vectors ---------------------------------------------------------------------------
  * Host <-> device copies in the caller's DoF numbering, (n,1) fp64 C-contiguous as the

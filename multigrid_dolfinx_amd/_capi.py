@@ -55,7 +55,7 @@ SIGNATURES = {
     "mg_set_restriction_table": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "mg_level_info": [_H, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _ip, _ip, _ip],
     "mg_level_row_classes": [_H, C.c_int, _ip],
-    "mg_level_storage": [_H, C.c_int, _ip, _i64p, _i64p, _ip, _ip],
+    "mg_level_storage": [_H, C.c_int, _ip, _i64p, _i64p, _ip, _ip, _i64p],
     "mg_set_vector": [_H, C.c_int, C.c_int, C.c_void_p],
     "mg_get_vector": [_H, C.c_int, C.c_int, C.c_void_p, C.c_int],
     "mg_zero_vector": [_H, C.c_int, C.c_int],

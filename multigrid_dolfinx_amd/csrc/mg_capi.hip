@@ -133,6 +133,9 @@ struct Level {
     // dictionary (-1: not built) and the tolerance it was built with
     int rep_sym = -1, rep_sym_qbits = 0, rep_cls_qbits = 0, rep_distinct = -1;
     int64_t rep_first_asym = -1, rep_max_ulps = 0;
+    bool cls_escape = false;     // rows of class CLS_ESCAPE exist: read from the stored row (K-sweep march only; other class kernels off)
+    int esc_kmax = 0;            // ... and the most sweeps per pass whose tiles' escape rows fit the march's pool (jk3_escape_window)
+    int64_t rep_escape = 0;      // ... how many
     int cls_halo = 0;            // row classes of the neighbours' planes next to this slab: 0 not built yet, 1 in place, -1 unavailable
     bool flat = false;           // no grid structure (stand-alone smoother on any matrix)
     int W = 0, R = 1;
@@ -253,6 +256,8 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    int gen_odd_rows = 0;           // "gen_odd_rows": mg_gen_poisson_level perturbs the diagonal of this many interior rows in 10000
+    int cls_escape = 1;             // "row_escape": more than 255 distinct rows -> the frequent ones as classes, the rest read from their stored row
     int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 4 ulps
     int storage_qbits = 0;          // "storage_ulps": low mantissa bits ignored by the symmetry test and the row dictionary
     int use_classes = 1;            // one class byte per row where a level has <= 255 distinct rows (two-sweep pass)
@@ -373,6 +378,9 @@ void vec_free(mg_context* c, const Level& L, DVector* v) {
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
+// every row of the level has a class from the table (no escapes): what all class kernels but the K-sweep march need
+inline bool cls_full(const Level& L) { return L.cls != nullptr && !L.cls_escape; }
+
 // one thread per node of a plane (x), owned planes (y); block = kPlaneBlock threads
 constexpr int kPlaneBlock = 256;
 dim3 grid3(const Grid& g, int nk) { return dim3((unsigned)((g.plane + kPlaneBlock - 1) / kPlaneBlock), (unsigned)nk, 1u); }
@@ -490,6 +498,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.cls, (size_t)L.cls_rows);
     dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
+    L.cls_escape = false; L.esc_kmax = 0; L.rep_escape = 0;
     L.cls_halo = 0;
     L.rep_sym = -1; L.rep_sym_qbits = L.rep_cls_qbits = 0; L.rep_distinct = -1; L.rep_first_asym = -1; L.rep_max_ulps = 0;
     dev_free(c, L.scls, (size_t)L.nslices * WAVE * L.R);
@@ -757,7 +766,7 @@ int launch_ell(mg_context* c, const Level& L, int mode, bool dot, const double* 
         if (grid_out) *grid_out = grid;
         const bool nt = c->nontemporal != 0;
         const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
-        if (L.cls && c->class_sweeps) {
+        if (cls_full(L) && c->class_sweeps) {
             // the rows through their classes: 25 instead of 56 bytes per row (mg_kernels.hip.h, sdia_cls_body);
             // persistent blocks (8 per CU, a multiple of 8 so that a block's groups stay on one XCD's share)
             a.cls = L.cls + L.cls_lead; a.ctab = L.ctab; a.ncls = L.ncls; a.cmain = L.cmain;
@@ -1022,7 +1031,7 @@ struct J2Plan { int ntx, nty, nseg, zb, seglen, wi; };
 // grid lines per tile: 16 for the plain pass; the class-coded pass has shapes with 16 and 32 ("fuse_shape")
 int jacobi2_lines(const mg_context* c, const Level& L) {
     const int sh = c->fuse_shape;
-    if (!(L.cls && c->fuse_classes)) return (c->fuse_plain == 2 && c->fuse_plain_shape == 0) ? 12 : kJ2Lines;
+    if (!(cls_full(L) && c->fuse_classes)) return (c->fuse_plain == 2 && c->fuse_plain_shape == 0) ? 12 : kJ2Lines;
     return (sh == 1 || sh == 3) ? 24 : kJ2Lines;
 }
 
@@ -1031,7 +1040,7 @@ J2Plan jacobi2_plan(const mg_context* c, const Level& L, bool slab, int64_t boun
     const int lines = jacobi2_lines(c, L);
     p.ntx = (L.g.nx + J2_EX - 3) / (J2_EX - 2);
     p.nty = (L.g.ny + lines - 3) / (lines - 2);
-    if ((L.cls && c->fuse_classes) || c->fuse_plain == 2) {
+    if ((cls_full(L) && c->fuse_classes) || c->fuse_plain == 2) {
         // class-coded pass / round-2 plain pass: the x ring is part of the tile (124 cells with a second sweep at most), and all tile
         // columns have the same width, the smallest that covers the grid ("fuse_even" 0: always the widest)
         p.ntx = (L.g.nx + J2_EX - 5) / (J2_EX - 4);
@@ -1151,7 +1160,7 @@ int launch_jacobi2(mg_context* c, const Level& L, const J2Plan& plan, int seg0, 
     const int n = count;
     // 8 waves x 2 grid lines each (16 waves x 1 line measured slower and does not fit 128 registers)
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
-    if (L.cls && c->fuse_classes) {
+    if (cls_full(L) && c->fuse_classes) {
         a.cls = L.cls; a.ctab = L.ctab; a.clead = L.cls_lead;
         a.ncls = L.ncls; a.cmain = L.cmain; a.wi = plan.wi;
         for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
@@ -1214,7 +1223,7 @@ int ensure_class_halos(mg_context* c, Level& L) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&trecv.p), 2 * nt * sizeof(double)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dmap.p), 2 * 256 * sizeof(int)));
     const unsigned nb = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
-    int ok = L.cls != nullptr && L.ncls > 0 && L.sdia && L.wu == 4 && L.up[1] == 1 && L.up[2] == L.g.nx && (int64_t)L.up[3] == L.g.plane ? 1 : 0;
+    int ok = cls_full(L) && L.ncls > 0 && L.sdia && L.wu == 4 && L.up[1] == 1 && L.up[2] == L.g.nx && (int64_t)L.up[3] == L.g.plane ? 1 : 0;
     std::vector<double> mine(nt, 0.0), theirs(2 * nt, 0.0);
     if (ok) {
         hipLaunchKernelGGL(bytes_to_doubles, dim3(nb), dim3(256), 0, c->stream, L.cls + L.cls_lead, send.p, (int64_t)n);
@@ -1279,6 +1288,11 @@ int ensure_class_halos(mg_context* c, Level& L) {
 // and slabs whose vectors have room for K halo planes ("halo_depth").
 bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     if (c->fuse_k < 3 || !L.cls || !c->fuse_classes) return false;
+    if (L.cls_escape) {
+        // (nothing else on such a level uses its classes: the march wherever it runs at all, whatever the level's size)
+        if (L.esc_kmax < 3) return false;
+        ignore_size = true;
+    }
     const bool slab = !L.replicated && c->comm.active();
     if (slab && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
     if (!ignore_size && (slab ? min_slab_rows(L) < c->fuse_k_slab_min_rows : L.nloc < c->fuse_k_min_rows)) return false;
@@ -1288,19 +1302,49 @@ bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
 // sweeps per pass on a whole level (with the 64 x 32 tiles of 16 waves five sweeps per pass measured best on 1025^3 and 513^3
 // rows, four on 257^3, profiles/r03_ksweep_levels.txt; "fuse_k4_min_rows" caps smaller levels at three)
 int sweepsk_max(const mg_context* c, const Level& L) {
-    return std::min(std::min(c->fuse_k, 5), L.nloc < c->fuse_k4_min_rows ? 3 : L.nloc < c->fuse_k5_min_rows ? 4 : 5);
+    const int k = std::min(std::min(c->fuse_k, 5), L.nloc < c->fuse_k4_min_rows ? 3 : L.nloc < c->fuse_k5_min_rows ? 4 : 5);
+    return L.cls_escape ? std::min(k, L.esc_kmax) : k;
+}
+
+// the most pool rows a tile of the escape variant of the march takes within K + 2 planes (jk3_escape_window)
+template <int K>
+int escape_window_k(mg_context* c, const Level& L, const unsigned char* cls, int64_t clead, unsigned* most) {
+    constexpr int WI = 64 - 2 * K, HY = 16 * 2 - 2 * K + 2;
+    JK3WindowArgs a{};
+    a.cls = cls; a.clead = clead; a.P = L.g.plane; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk;
+    a.ntx = (a.nx + WI - 1) / WI; a.nty = (a.ny + HY - 1) / HY;
+    a.most = reinterpret_cast<unsigned*>(c->partials);
+    HIP_TRY(hipMemsetAsync(a.most, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL((jk3_escape_window<K, 16, 2, 1>), dim3((unsigned)(a.ntx * a.nty)), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(most, a.most, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int escape_kmax(mg_context* c, const Level& L, const unsigned char* cls, int64_t clead, int* kmax) {
+    *kmax = 0;
+    if (L.wu != 4 || L.g.nk < 8 || L.g.nx < 32 || L.g.ny < 32) return 0;
+    unsigned most = 0;
+    MG_TRY(escape_window_k<5>(c, L, cls, clead, &most));
+    if (most <= (unsigned)jk3_pool(5)) { *kmax = 5; return 0; }
+    MG_TRY(escape_window_k<4>(c, L, cls, clead, &most));
+    if (most <= (unsigned)jk3_pool(4)) { *kmax = 4; return 0; }
+    MG_TRY(escape_window_k<3>(c, L, cls, clead, &most));
+    if (most <= (unsigned)jk3_pool(3)) *kmax = 3;
+    return 0;
 }
 
 // plane ranges of one launch of the march: [za0, za1) and then [zb0, zb1)
 struct JK3Range { int za0, za1, zb0, zb1; };
 
-template <int K, int NW, int LPW, int M, bool DPP, int PF = 1, int WPE = (NW == 12 ? 3 : 2), int TR = 256>
+template <int K, int NW, int LPW, int M, bool DPP, int PF = 1, int WPE = (NW == 12 ? 3 : 2), int TR = 256, bool ESC = false>
 int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest, const JK3Range& zr, int seglen) {
     constexpr int EX = 64 * M, EY = NW * LPW, WI = EX - 2 * K, HY = EY - 2 * K + 2;
     a.ntx = (a.nx + WI - 1) / WI;
     a.nty = (a.ny + HY - 1) / HY;
     const int64_t ntile = (int64_t)a.ntx * a.nty;
-    constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M, TR>();
+    constexpr size_t lds = jk3_lds_bytes<K, NW, LPW, M, TR, ESC>();
     static_assert(lds <= 160 * 1024, "one CU's LDS");
     a.za0 = zr.za0; a.za1 = zr.za1; a.zb0 = zr.zb0; a.zb1 = zr.zb1;
     const int planes = std::max(0, zr.za1 - zr.za0) + std::max(0, zr.zb1 - zr.zb0);
@@ -1345,9 +1389,10 @@ int launch_jacobikc_t(mg_context* c, JK3Args a, bool finest, const JK3Range& zr,
     const int64_t group = 8 * (int64_t)a.xcd_chunk;
     const unsigned grid = (unsigned)(((items + group - 1) / group) * group);
     if (a.ncls > TR) return fail("more row classes than this tile shape keeps in LDS");
-    void (*const kern[2])(JK3Args) = {sdia_jacobikc<K, NW, LPW, M, DPP, PF, WPE, TR>, sdia_jacobikc_finest<K, NW, LPW, M, DPP, PF, WPE, TR>};
-    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern[finest ? 1 : 0]), lds));
-    hipLaunchKernelGGL(kern[finest ? 1 : 0], dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
+    void (*kern)(JK3Args) = finest ? sdia_jacobikc_finest<K, NW, LPW, M, DPP, PF, WPE, TR> : sdia_jacobikc<K, NW, LPW, M, DPP, PF, WPE, TR>;
+    if constexpr (ESC) kern = sdia_jacobikc_escape<K, NW, LPW, M, DPP, PF, WPE, TR>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * WAVE), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1377,6 +1422,11 @@ int launch_jacobikc_kp(mg_context* c, const JK3Args& a, bool finest, const JK3Ra
 
 template <int K>
 int launch_jacobikc_k(mg_context* c, const JK3Args& a, bool finest, const JK3Range& zr, int seglen) {
+    // levels with rows of class CLS_ESCAPE: the variant that fetches them, one tile shape (the one escape_window() checked)
+    if (a.escape) {
+        if constexpr (K >= 3) return launch_jacobikc_t<K, 16, 2, 1, true, 1, 4, 256, true>(c, a, finest, zr, seglen);
+        else return fail("levels with escape rows take three to five sweeps per pass");
+    }
     // a second plane of x staged in registers ("fuse_k_pf" 2) fits the register budget with three sweeps only
     if constexpr (K == 3 || K == 4) {
         if (c->fuse_k_pf == 2 && (K == 3 || c->fuse_k_shape == 7)) return launch_jacobikc_kp<K, 2>(c, a, finest, zr, seglen);
@@ -1399,8 +1449,10 @@ int launch_jacobikc(mg_context* c, const Level& L, int K, const double* x_rows, 
     a.plo = dist && c->comm.rank > 0 ? K : 0;
     a.phi = dist && c->comm.rank + 1 < c->comm.world ? K : 0;
     if (dist && (L.hd < K || L.cls_halo != 1)) return fail("the level's halos are not prepared for that many sweeps per pass");
+    if (L.cls_escape && K > L.esc_kmax) return fail("too many escape rows per tile for that many sweeps per pass");
     a.force_form = c->timing_force_form;
     a.nt_store = c->fuse_k_nt_store;
+    a.escape = L.cls_escape ? 1 : 0; a.dvals = L.dvals; a.mlead = L.mlead; a.sshift = L.R == 1 ? 6 : (L.R == 2 ? 7 : 8);
     const JK3Range whole{0, L.g.nk, 0, 0};
     const bool finest = c->nlev > 1 && &L == &c->L[c->nlev - 1];
     switch (K) {
@@ -1447,7 +1499,7 @@ int check_coloring(mg_context* c, Level& L) {
 // K sweeps per launch on 2-D levels (mg_jacobi2.hip.h, sdia_jacobik2d): whole, undistributed five-point levels
 // with row classes whose stored diagonals are exactly {0, +1, +nx}.
 bool sweeps2d_ok(const mg_context* c, const Level& L) {
-    if (!c->fuse_2d || !L.sdia || L.wu != 3 || !L.cls || !c->fuse_classes || L.flat || !L.replicated) return false;
+    if (!c->fuse_2d || !L.sdia || L.wu != 3 || !cls_full(L) || !c->fuse_classes || L.flat || !L.replicated) return false;
     return L.g.ny == 1 && L.up[1] == 1 && L.up[2] == L.g.nx && L.g.nx >= 8 && L.g.nz >= 8;
 }
 
@@ -1485,7 +1537,7 @@ int launch_jacobik(mg_context* c, const Level& L, int K, const double* x_rows, c
 // One sweep as a plane march (sdia_sweep1c): whole, undistributed 3-D seven-point levels with row classes, large enough
 // for the march to pay ("march_min_rows").
 bool sweep1c_ok(const mg_context* c, const Level& L) {
-    if (!c->march_sweeps || !L.cls || !c->class_sweeps || !L.sdia || L.wu != 4 || L.flat || !L.replicated) return false;
+    if (!c->march_sweeps || !cls_full(L) || !c->class_sweeps || !L.sdia || L.wu != 4 || L.flat || !L.replicated) return false;
     if (L.g.nx < 32 || L.g.ny < 32 || L.g.nk < 8) return false;
     if (L.up[1] != 1 || L.up[2] != L.g.nx || (int64_t)L.up[3] != L.g.plane) return false;
     return L.nloc >= c->march_min_rows;
@@ -1538,7 +1590,7 @@ int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows
 // All sweeps of a small level in one launch (mg_jacobi2.hip.h, sdia_jacobi_small): whole five- / seven-point levels with
 // row classes that fit one CU's LDS.
 bool small_level_ok(const mg_context* c, const Level& L) {
-    if (!c->fuse_small || !L.sdia || !L.cls || !c->fuse_classes || L.flat || !L.replicated) return false;
+    if (!c->fuse_small || !L.sdia || !cls_full(L) || !c->fuse_classes || L.flat || !L.replicated) return false;
     if (L.wu != 3 && L.wu != 4) return false;
     if (L.up[1] != 1 || L.up[2] <= 1 || (L.wu == 4 && L.up[3] <= L.up[2])) return false;
     const int pad = L.wu == 4 ? L.up[3] : L.up[2];
@@ -1681,7 +1733,7 @@ int smooth(mg_context* c, int level, int nw) {
             nw = left;
         }
     }
-    if (!dist && fused && nw >= 3 && sweepsk_ok(c, L)) {
+    if (!dist && (fused || L.cls_escape) && nw >= 3 && sweepsk_ok(c, L)) {
         // whole levels: K sweeps per pass while that leaves no single sweep over (50 = 12 x 4 + 2, 7 = 4 + 3, 5 = 3 + 2)
         const int kmax = sweepsk_max(c, L);
         int left = nw;
@@ -1854,7 +1906,7 @@ int residual_restrict_fused(mg_context* c, int level) {
     if (F.sdia) {
         a.vals = F.dvals; a.W = F.wu; a.coded = 2; a.mlead = F.mlead;
         for (int t = 0; t < 8; ++t) a.up[t] = F.up[t];
-        if (F.cls && c->class_sweeps) {
+        if (cls_full(F) && c->class_sweeps) {
             a.coded = 3; a.cls = F.cls + F.cls_lead; a.ctab = F.ctab;
         }
     }
@@ -2368,12 +2420,70 @@ int build_row_classes_q(mg_context* c, Level& L, int qbits) {
         return 0;
     }();
     if (!rc) { L.rep_distinct = h[0]; L.rep_cls_qbits = qbits; }
+    bool escape = false;
+    if (!rc && (h[0] > 255 || h[1]) && c->cls_escape && L.wu == 4 && !L.flat && L.nloc >= (1 << 16)) {
+        // More than 255 distinct rows.  If most rows are still copies of a few (a uniform mesh with some odd rows: other
+        // material, other boundary condition), the 254 most frequent rows -- found on a sample of 2^20 rows spread over the
+        // level -- keep their class bytes and every other row gets CLS_ESCAPE: the K-sweep march reads such a row from the
+        // symmetric diagonal storage.  Worth it while at least three quarters of the rows have a class.
+        rc = [&]() -> int {
+            unsigned* slot_count = nullptr;
+            struct Free { unsigned*& p; ~Free() { if (p) (void)hipFree(p); } } guard{slot_count};
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot_count), CLS_SLOTS * sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(slot_count, 0, CLS_SLOTS * sizeof(unsigned), c->stream));
+            HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + val_bytes + int_bytes, c->stream));
+            const int64_t nsample = std::min<int64_t>(L.nloc, (int64_t)1 << 20);
+            const dim3 sgrid(blocks_for(nsample, 256));
+            switch (L.R) {
+                case 1: hipLaunchKernelGGL(cls_sample_insert<64>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
+                case 2: hipLaunchKernelGGL(cls_sample_insert<128>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
+                default: hipLaunchKernelGGL(cls_sample_insert<256>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
+            }
+            HIP_TRY(hipGetLastError());
+            std::vector<unsigned> cnt(CLS_SLOTS);
+            std::vector<double> sv((size_t)CLS_SLOTS * CLS_W);
+            HIP_TRY(hipMemcpyAsync(cnt.data(), slot_count, CLS_SLOTS * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(sv.data(), a.svals, val_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            std::vector<int> order(CLS_SLOTS);
+            for (int i = 0; i < CLS_SLOTS; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+            std::vector<int> slot_class(CLS_SLOTS, 0);
+            std::fill(tab.begin(), tab.end(), 0.0);
+            for (int id = 1; id < CLS_ESCAPE && cnt[order[id - 1]] > 0; ++id) {
+                slot_class[order[id - 1]] = id;
+                for (int t = 0; t < 7; ++t) tab[(size_t)CLS_W * id + t] = sv[(size_t)CLS_W * order[id - 1] + t];
+            }
+            HIP_TRY(hipMemcpyAsync(a.slot_class, slot_class.data(), CLS_SLOTS * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(ctab, tab.data(), 256 * CLS_W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemsetAsync(a.hist, 0, 256 * sizeof(unsigned), c->stream));
+            switch (L.R) {
+                case 1: hipLaunchKernelGGL(cls_encode_escape<64>, egrid, blk, 0, c->stream, a); break;
+                case 2: hipLaunchKernelGGL(cls_encode_escape<128>, egrid, blk, 0, c->stream, a); break;
+                default: hipLaunchKernelGGL(cls_encode_escape<256>, egrid, blk, 0, c->stream, a); break;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(hist.data(), a.hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return 0;
+        }();
+        escape = !rc && (double)hist[CLS_ESCAPE] <= 0.25 * (double)L.nloc;
+        int kmax = 0;
+        // ... and no tile of the march meets more of them at a time than its pool holds
+        if (escape && hist[CLS_ESCAPE] > 0) {
+            rc = escape_kmax(c, L, cls, cls_lead, &kmax);
+            escape = !rc && kmax >= 3;
+        }
+        if (escape) { h[0] = 254; h[1] = 0; L.esc_kmax = kmax; L.rep_escape = hist[CLS_ESCAPE]; }
+    }
     if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass
         dev_free(c, cls, (size_t)cls_rows);
         dev_free(c, ctab, 256 * CLS_W);
         return rc;
     }
     L.cls = cls; L.ctab = ctab; L.ncls = h[0] + 1; L.cls_lead = cls_lead; L.cls_rows = cls_rows;
+    L.cls_escape = escape && L.rep_escape > 0;
+    if (escape) hist[CLS_ESCAPE] = 0;               // (never the most frequent class)
     L.cmain = 0;
     for (int k = 1; k < L.ncls; ++k)
         if (L.cmain == 0 || hist[k] > hist[L.cmain]) L.cmain = k;
@@ -2874,6 +2984,13 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         int q = 0;
         while ((1ll << q) < value) ++q;
         c->storage_qbits = value > 0 ? std::max(1, q) : 0;
+    } else if (k == "gen_odd_rows") {
+        if (value < 0 || value > 10000) return fail("gen_odd_rows: rows in 10000");
+        c->gen_odd_rows = (int)value;
+    } else if (k == "row_escape") {
+        for (auto& L : c->L)
+            if (L.set) return fail("row_escape must be chosen before level set-up");
+        c->cls_escape = value != 0;
     } else if (k == "storage_auto") {
         for (auto& L : c->L)
             if (L.set) return fail("storage_auto must be chosen before level set-up");
@@ -3209,7 +3326,7 @@ int mg_gen_poisson_level(mg_handle c, int level, int N, int prune_zeros) {
     free_level(c, L);
     MG_TRY(setup_geometry(c, L, level, N));
     GenArgs a{};
-    a.g = L.g; a.N = N; a.dim = c->dim; a.prune = prune_zeros;
+    a.g = L.g; a.N = N; a.dim = c->dim; a.prune = prune_zeros; a.odd = c->gen_odd_rows;
     a.h = 1.0 / (double)N;
     a.w = c->dim == 2 ? 1.0 : a.h;
     a.diag = c->dim == 2 ? 4.0 : 6.0 * a.h;
@@ -3358,13 +3475,14 @@ int mg_level_info(mg_handle c, int level, int64_t* n_global, int64_t* n_local, i
 }
 
 int mg_level_storage(mg_handle c, int level, int* symmetric, int64_t* first_asymmetric_row, int64_t* max_pair_ulps,
-                     int* distinct_rows, int* ulps_used) {
+                     int* distinct_rows, int* ulps_used, int64_t* escape_rows) {
     MG_TRY(check_level(c, level));
     const Level& L = c->L[level];
     if (symmetric) *symmetric = L.rep_sym;
     if (first_asymmetric_row) *first_asymmetric_row = L.rep_first_asym;
     if (max_pair_ulps) *max_pair_ulps = L.rep_max_ulps;
     if (distinct_rows) *distinct_rows = L.rep_distinct;
+    if (escape_rows) *escape_rows = L.cls_escape ? L.rep_escape : 0;
     if (ulps_used) *ulps_used = std::max(L.sdia ? (L.rep_sym_qbits ? 1 << L.rep_sym_qbits : 0) : 0, L.cls ? (L.rep_cls_qbits ? 1 << L.rep_cls_qbits : 0) : 0);
     return 0;
 }

@@ -406,6 +406,82 @@ __global__ void cls_assign(ClsArgs a) {
         for (int c = 0; c < CLS_W; ++c) a.ctab[CLS_W * id + c] = 0.0;
 }
 
+// ---- more than 255 distinct rows: the frequent rows as classes, the others "escape" to their stored row -----------------
+// (class CLS_ESCAPE: the K-sweep march reads such a row from the symmetric diagonal storage; the other class kernels leave
+// a level with escapes alone.)  Which rows are frequent is found on a SAMPLE spread over the level -- a row that occurs with
+// frequency p is in the table after ~1/p samples, long before rare rows have filled it --, with an occurrence count per slot.
+constexpr int CLS_ESCAPE = 255;
+
+template <int S>
+__global__ void cls_sample_insert(ClsArgs a, int64_t nsample, unsigned* slot_count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsample) return;
+    const int64_t row = (int64_t)(((unsigned long long)t * 0x9e3779b97f4a7c15ull >> 11) % (unsigned long long)a.nloc);
+    unsigned long long b[7];
+    cls_row<S>(a, row, b);
+    if (cls_zero(b)) return;
+    const unsigned long long h = cls_hash(b, a.qbits);
+    unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+    for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+        const unsigned long long seen = *(volatile unsigned long long*)(a.tags + s);
+        if (seen == h) { atomicAdd(slot_count + s, 1u); return; }
+        if (seen != 0ull) { s = (s + 1) & (CLS_SLOTS - 1); continue; }
+        if (*(volatile int*)a.count >= (CLS_SLOTS * 3) / 4) return;           // table as full as it gets: a rare row
+        const unsigned long long old = atomicCAS(a.tags + s, 0ull, h);
+        if (old == 0ull) {
+#pragma unroll
+            for (int c = 0; c < 7; ++c) a.svals[CLS_W * s + c] = __longlong_as_double((long long)b[c]);
+            atomicAdd(a.count, 1);
+            atomicAdd(slot_count + s, 1u);
+            return;
+        }
+        if (old == h) { atomicAdd(slot_count + s, 1u); return; }
+        s = (s + 1) & (CLS_SLOTS - 1);
+    }
+}
+
+// every row: its class if its row is one of the chosen ones (slot_class, bit for bit or within the tolerance), else CLS_ESCAPE
+template <int S>
+__global__ __launch_bounds__(256) void cls_encode_escape(ClsArgs a) {
+    __shared__ unsigned s_hist[256];
+    s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.crows) {
+        const int64_t row = i - a.clead;
+        int id = 0;
+        if (row >= 0 && row < a.nloc) {
+            unsigned long long b[7];
+            cls_row<S>(a, row, b);
+            if (!cls_zero(b)) {
+                id = CLS_ESCAPE;
+                const unsigned long long h = cls_hash(b, a.qbits);
+                unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+                for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+                    const unsigned long long t = a.tags[s];
+                    if (t == h) {
+                        bool same = true;
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) {
+                            const long long sv = __double_as_longlong(a.svals[CLS_W * s + c]), bv = (long long)b[c];
+                            const long long d = sv - bv;
+                            same = same && (sv == bv || (a.qbits > 0 && (sv < 0) == (bv < 0) && (d < 0 ? -d : d) <= (1ll << a.qbits)));
+                        }
+                        if (same && a.slot_class[s] != 0) id = a.slot_class[s];
+                        break;
+                    }
+                    if (t == 0ull) break;
+                    s = (s + 1) & (CLS_SLOTS - 1);
+                }
+            }
+            atomicAdd(&s_hist[id], 1u);
+        }
+        a.cls[i] = (unsigned char)id;
+    }
+    __syncthreads();
+    if (s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void cls_encode(ClsArgs a) {
     __shared__ unsigned s_hist[256];

@@ -63,12 +63,30 @@ struct JK3Args {
     int ta, seglen_b;
     unsigned nitems, xcd_chunk;
     int nt_store;               // 1: non-temporal stores of the result
+    // rows of class CLS_ESCAPE (mg_jacobi2.hip.h): read from the symmetric diagonal storage, slices of 1 << sshift rows
+    int escape;                 // 1: the level has such rows
+    const double* dvals;
+    int64_t mlead;
+    int sshift;
     int force_form;             // -1; timing experiments (mg_time_kernel only, results are wrong): every step in form 0 / 1 / 2
 };
 
+// Rows of class CLS_ESCAPE (levels with more than 255 distinct rows, mg_jacobi2.hip.h): when a plane arrives, every lane
+// that holds such a row fetches its seven entries from the symmetric diagonal storage into a row of a POOL behind the
+// class table -- rows handed out in turn, workgroup-wide, through an LDS counter -- and goes on with the pool row's number
+// as the cell's class: the general form of the step then finds the entries where it finds those of any class.  A pool row
+// is needed for the K + 1 steps its plane stays in the ring; the host checks (jk3_escape_window) that no tile ever takes
+// more than jk3_pool(K) rows within K + 2 consecutive planes before it lets a level use the march.
+// (a power of two that fits next to the K plane images of the 64 x 32 tiles: 64 KB, 32 KB with five images)
+constexpr int jk3_pool(int K) { return K >= 5 ? 512 : 1024; }
+
 // (TR: rows of the class table kept in LDS -- 256, or 64 for the shapes that run two workgroups per CU)
-template <int K, int NW, int LPW, int M, int TR> constexpr size_t jk3_lds_bytes() {
-    return sizeof(double) * (TR * CLS_W + (size_t)K * (NW * LPW + 2) * (64 * M) + 2 * (64 * M + 2));
+template <int K, int NW, int LPW, int M, int TR> constexpr size_t jk3_lds_doubles() {
+    return TR * CLS_W + (size_t)K * (NW * LPW + 2) * (64 * M) + 2 * (64 * M + 2);
+}
+template <int K, int NW, int LPW, int M, int TR, bool ESC = false> constexpr size_t jk3_lds_bytes() {
+    constexpr size_t base = jk3_lds_doubles<K, NW, LPW, M, TR>();
+    return sizeof(double) * (ESC ? (base + CLS_W - 1) / CLS_W * CLS_W + (size_t)(jk3_pool(K) + 1) * CLS_W : base);
 }
 
 // the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
@@ -83,9 +101,14 @@ __device__ __forceinline__ double jk3_from_east(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int K, int NW, int LPW, int M, bool DPP, int PF, int TR>
+template <int K, int NW, int LPW, int M, bool DPP, int PF, int TR, bool ESC = false>
 __device__ __forceinline__ void jk3_body(const JK3Args& a) {
-    constexpr int EX = 64 * M, EY = NW * LPW, NC = M * LPW, IMG = (EY + 2) * EX, CW = (NC + 3) / 4;
+    constexpr int EX = 64 * M, EY = NW * LPW, NC = M * LPW, IMG = (EY + 2) * EX;
+    // classes in the ring: a byte per cell, four cells to a register -- sixteen bits where pool rows are classes too
+    constexpr int CBITS = ESC ? 16 : 8, CPR = 32 / CBITS, CW = (NC + CPR - 1) / CPR;
+    constexpr unsigned CMASK = (1u << CBITS) - 1u;
+    constexpr int DYN0 = (int)((jk3_lds_doubles<K, NW, LPW, M, TR>() + CLS_W - 1) / CLS_W);   // the pool's first row, counted from sT
+    static_assert(CLS_W == 8, "table rows of eight doubles");
     constexpr int WI = EX - 2 * K, HY = EY - 2 * K + 2;       // cells per line / lines of a tile that get all K sweeps
     static_assert(NC * (K + 1) <= 64, "the fast-path flags live in one scalar register pair");
     static_assert(WI > 0 && HY > 0, "tile too small for K sweeps");
@@ -134,6 +157,10 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             sT[i] = v;
         }
         for (int i = threadIdx.x; i < K * IMG + 2 * (EX + 2); i += NW * WAVE) sT[TR * CLS_W + i] = 0.0;
+    }
+    unsigned* const esc_count = reinterpret_cast<unsigned*>(sT + (size_t)CLS_W * (DYN0 + jk3_pool(K)));   // (ESC) pool rows handed out so far
+    if constexpr (ESC) {
+        if (threadIdx.x == 0) *esc_count = 0u;
     }
     const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
     const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
@@ -252,12 +279,12 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             for (int r = 0; r < M; ++r) hy[r] = ldd(xb, eor[r]);
         }
     };
-    auto cls_of = [&](int j, int c) -> int { return (int)((cw[j][c >> 2] >> (8 * (c & 3))) & 255u); };
+    auto cls_of = [&](int j, int c) -> int { return (int)((cw[j][c / CPR] >> (CBITS * (c % CPR))) & CMASK); };
     // (general form: extracted anew at every use -- kept, the table addresses of all cells and ring planes cost 20 registers)
     auto cls_now = [&](int j, int c) -> int {
-        unsigned w = cw[j][c >> 2];
+        unsigned w = cw[j][c / CPR];
         asm volatile("" : "+v"(w));
-        return (int)((w >> (8 * (c & 3))) & 255u);
+        return (int)((w >> (CBITS * (c % CPR))) & CMASK);
     };
     int k_plane = 0;            // the step: plane whose result it stores, whether it stores, the plane's base in `out`
     bool k_store = false;
@@ -434,13 +461,42 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             asm volatile("" : "+v"(X[c]));
             C[c] &= 255;
         }
+        if constexpr (ESC) {
+            // rows of class CLS_ESCAPE: their entries into pool rows, the pool row as the cell's class (see jk3_pool)
+            if (a.escape) {
+                const int64_t mp = (int64_t)min(max(k + K, pmin), pmax) * a.P - bias + a.mlead;
+                const int sh = a.sshift;
+                const double* const dv = a.dvals;
+                auto at = [&](int64_t m, int slot) -> double { return dv[((((m >> sh) << 2) + slot) << sh) + (m & (((int64_t)1 << sh) - 1))]; };
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const unsigned long long em = __ballot(C[c] == CLS_ESCAPE);
+                    if (em != 0ull) {
+                        unsigned b0 = 0u;
+                        if (lane == 0) b0 = atomicAdd(esc_count, (unsigned)__popcll(em));
+                        b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                        if (C[c] == CLS_ESCAPE) {
+                            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+                            const int row = DYN0 + (int)((b0 + below) & (unsigned)(jk3_pool(K) - 1));
+                            const int64_t m = mp + (int64_t)(eo[c] >> 3);
+                            const double e0 = at(m - a.P, 3), e1 = at(m - a.nx, 2), e2 = at(m - 1, 1);
+                            const double e3 = at(m, 0), e4 = at(m, 1), e5 = at(m, 2), e6 = at(m, 3);
+                            double* const tr = sT + CLS_W * row;
+                            tr[0] = e0; tr[1] = e1; tr[2] = e2; tr[3] = e3; tr[4] = e4; tr[5] = e5; tr[6] = e6;
+                            tr[7] = a.omega * (1.0 / (e3 != 0.0 ? e3 : 1.0));
+                            C[c] = row;
+                        }
+                    }
+                }
+            }
+        }
         {
             unsigned m = 0;
 #pragma unroll
             for (int q = 0; q < CW; ++q) cw[K][q] = 0u;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                cw[K][c >> 2] |= (unsigned)C[c] << (8 * (c & 3));
+                cw[K][c / CPR] |= (unsigned)C[c] << (CBITS * (c % CPR));
                 if (__builtin_amdgcn_readfirstlane((int)(__ballot(C[c] != cmain) == 0ull))) m |= 1u << c;
             }
             fast |= (unsigned long long)m << (K * NC);
@@ -540,6 +596,50 @@ template <int K, int NW, int LPW, int M, bool DPP, int PF, int WPE, int TR>
 __global__ __attribute__((amdgpu_flat_work_group_size(NW * WAVE, NW * WAVE), amdgpu_waves_per_eu(WPE, WPE)))
 void sdia_jacobikc_finest(JK3Args a) {
     jk3_body<K, NW, LPW, M, DPP, PF, TR>(a);
+}
+
+// (levels with rows of class CLS_ESCAPE)
+template <int K, int NW, int LPW, int M, bool DPP, int PF, int WPE, int TR>
+__global__ __attribute__((amdgpu_flat_work_group_size(NW * WAVE, NW * WAVE), amdgpu_waves_per_eu(WPE, WPE)))
+void sdia_jacobikc_escape(JK3Args a) {
+    jk3_body<K, NW, LPW, M, DPP, PF, TR, true>(a);
+}
+
+// The most pool rows any tile of the march <K, NW, LPW, M> takes within K + 2 consecutive planes: one workgroup per tile
+// counts the cells of class CLS_ESCAPE plane by plane -- the tile's cells at the very rows the march reads their classes
+// from (clamped like its byte offsets `eo`) -- and keeps the largest sum over a window of planes.
+struct JK3WindowArgs {
+    const unsigned char* cls;
+    int64_t clead, P;
+    int nx, ny, nz, ntx, nty;
+    unsigned* most;
+};
+
+template <int K, int NW, int LPW, int M>
+__global__ __launch_bounds__(256) void jk3_escape_window(JK3WindowArgs a) {
+    constexpr int EX = 64 * M, EY = NW * LPW, WI = EX - 2 * K, HY = EY - 2 * K + 2, W = K + 2;
+    __shared__ unsigned s_ring[W], s_plane;
+    const int tiy = (int)(blockIdx.x / (unsigned)a.ntx), tix = (int)(blockIdx.x % (unsigned)a.ntx);
+    const int tx0 = tix * WI - K, ty0 = tiy * HY - (K - 1), xcl = a.nx + 1 - tx0;
+    unsigned win = 0u, best = 0u;
+    for (int p = 0; p < a.nz; ++p) {
+        if (threadIdx.x == 0) s_plane = 0u;
+        __syncthreads();
+        unsigned n = 0u;
+        for (int i = threadIdx.x; i < EX * EY; i += 256) {
+            const int ex = i % EX, ey = i / EX;
+            const int64_t row = (int64_t)p * a.P + (int64_t)min(max(ty0 + ey, -2), a.ny + 1) * a.nx + tx0 + min(ex, xcl);
+            n += a.cls[a.clead + row] == CLS_ESCAPE ? 1u : 0u;
+        }
+        if (n) atomicAdd(&s_plane, n);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            win += s_plane - (p >= W ? s_ring[p % W] : 0u);
+            s_ring[p % W] = s_plane;
+            best = max(best, win);
+        }
+    }
+    if (threadIdx.x == 0 && best) atomicMax(a.most, best);
 }
 
 }  // namespace mgk

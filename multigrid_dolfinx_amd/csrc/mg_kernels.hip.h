@@ -1124,7 +1124,20 @@ struct GenArgs {
     double h, w, diag, fh;   // h = 1/N, axis coupling magnitude, interior diagonal, f*h^dim
     int noff;
     int off[15][3];     // sorted pattern offsets (di, dj, dk) in unified (x, y, z) axes
+    int odd;            // "gen_odd_rows": of 10000 interior rows, picked by a hash of their grid index, this many get a
+                        // reaction term of their own on the diagonal (rows unlike any other: what the escape rows of the
+                        // row dictionary are measured on)
 };
+
+// the diagonal of interior row (i, j, k): a.diag, or a.diag * (1 + r), 0 <= r < 1 from the row's hash, for the odd rows
+__device__ __forceinline__ double gen_diag(const GenArgs& a, int i, int j, int k) {
+    if (a.odd <= 0) return a.diag;
+    unsigned long long x = ((unsigned long long)k * (unsigned long long)a.g.ny + (unsigned long long)j) * (unsigned long long)a.g.nx + (unsigned long long)i;
+    x += 0x9e3779b97f4a7c15ull;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    if ((int)(x % 10000ull) >= a.odd) return a.diag;
+    return a.diag * (1.0 + (double)((x >> 32) & 0xfffffull) / 1048576.0);
+}
 
 __device__ __forceinline__ double gen_g(const GenArgs& a, int i, int j, int k) {
     const double x = (double)i / (double)a.N;
@@ -1165,7 +1178,7 @@ __global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, do
             const int naxis = (di != 0) + (dj != 0) + (dk != 0);
             double v;
             if (naxis == 0) {
-                v = bnd ? 1.0 : a.diag;
+                v = bnd ? 1.0 : gen_diag(a, i, j, k);
             } else if (naxis == 1) {
                 const bool nb = gen_on_boundary(a, ii, jj, kk);
                 v = (!bnd && !nb) ? -a.w : 0.0;
@@ -1182,7 +1195,7 @@ __global__ void gen_poisson(GenArgs a, double* vals, int* cols, double* dinv, do
             }
             ++kept;
         }
-        dinv[lr] = 1.0 / (bnd ? 1.0 : a.diag);
+        dinv[lr] = 1.0 / (bnd ? 1.0 : gen_diag(a, i, j, k));
         f[lr] = b;
     }
     // one atomic pair per wave; counts[0] = stored entries, counts[1] = non-zero entries

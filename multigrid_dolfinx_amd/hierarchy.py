@@ -357,13 +357,14 @@ class DeviceHierarchy:
         """How the level's matrix got its storage (`mg_level_storage`): `symmetric` 1 = bit for bit, 2 = within
         `ulps_used` units in the last place, 0 = not (then `first_asymmetric_row`, in lexicographic numbering, and
         `max_pair_ulps`, -1 for a pair with one half missing, say why), -1 = not tested; `distinct_rows` seen by the row
-        dictionary (more than 255: no row classes), -1 = not built."""
+        dictionary (more than 255: no row classes, or -- `escape_rows` > 0 -- classes for the frequent rows and that many
+        rows read from the stored matrix), -1 = not built."""
         sym, rows, used = C.c_int(), C.c_int(), C.c_int()
-        first, spread = C.c_int64(), C.c_int64()
+        first, spread, esc = C.c_int64(), C.c_int64(), C.c_int64()
         check(self._lib.mg_level_storage(self._h, self._idx(level), C.byref(sym), C.byref(first), C.byref(spread),
-                                         C.byref(rows), C.byref(used)))
+                                         C.byref(rows), C.byref(used), C.byref(esc)))
         return {"symmetric": int(sym.value), "first_asymmetric_row": int(first.value), "max_pair_ulps": int(spread.value),
-                "distinct_rows": int(rows.value), "ulps_used": int(used.value)}
+                "distinct_rows": int(rows.value), "ulps_used": int(used.value), "escape_rows": int(esc.value)}
 
     def memory_bytes(self) -> int:
         b = C.c_int64()

@@ -1317,6 +1317,73 @@ def test_row_classes_fall_back_when_there_are_too_many_distinct_rows():
         assert np.array_equal(outs[0], outs[1]), case
 
 
+@pytest.mark.parametrize("case", ["diagonal", "scaled", "patch10", "patch16"])
+def test_escape_rows_keep_the_class_path(case):
+    """A uniform-mesh matrix with some odd rows has more than 255 distinct rows but is still mostly copies of a few: the
+    254 most frequent rows keep their classes, the others ("escape rows") are fetched from the stored matrix by the K-sweep
+    march (mg_jacobik3d.hip.h, JK3_POOL), and the level stays on the class path -- same arithmetic as single sweeps on the
+    stored rows, bit for bit, and equal to the oracle's Jacobi relaxation on the same matrix.
+      diagonal  1 % of the rows, picked at random, with their diagonal entry perturbed
+      scaled    D A D with 1 % of D's entries random powers of two (seven rows change per entry; symmetric bit for bit)
+      patch10   a 10 x 10 x 10 block of perturbed rows: one tile meets 100 of them per plane, which fits the march's pool
+                (1024 rows, 512 with five sweeps per pass) for four sweeps per pass (six planes) but not for five (seven)
+      patch16   16 x 16 x 16: too many for any pass -- the level goes without classes, as before"""
+    import scipy.sparse as sps
+    from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+    from oracle.mg_oracle import get_jacobi_matrices, jacobi_relaxation
+    rng = np.random.default_rng(5)
+    bag = poisson.make_hierarchy(3, 1, 3, c=8, mu1=2, mu2=2, seed=None)         # 65^3 unknowns on the finest level
+    A = bag.A_sp_dict[3][0].tocsr().copy()
+    n = A.shape[0]
+    odd = np.zeros(n, dtype=bool)
+    if case in ("diagonal", "scaled"):
+        odd[rng.choice(n, n // 100, replace=False)] = True
+    else:
+        w = 10 if case == "patch10" else 16
+        g = np.zeros((65, 65, 65), dtype=bool)
+        g[20:20 + w, 30:30 + w, 25:25 + w] = True
+        odd = g.ravel()[np.asarray(bag.levels[3].grid_index)]
+    if case == "scaled":
+        d = np.where(odd, 2.0 ** rng.integers(-20, 21, n), 1.0)
+        B = (sps.diags(d) @ A @ sps.diags(d)).tocsr()
+    else:
+        B = (A + sps.diags(np.where(odd, rng.uniform(0.1, 1.0, n) * A.diagonal(), 0.0))).tocsr()
+    v_in = rng.standard_normal((n, 1))
+    f_in = rng.standard_normal((n, 1))
+    outs = {}
+    for escape in (1, 0):
+        with DeviceHierarchy(3, 1, 3, c=8, row_escape=escape) as dev:
+            if not escape:
+                dev.set_tuning("fuse_sweeps", 0)                                # single sweeps on the stored rows
+            for l in (1, 2):
+                dev.set_level(l, bag.A_sp_dict[l][0], bag.levels[l].grid_index)
+            dev.set_level(3, B, bag.levels[3].grid_index)
+            dev.set_params(4, 4, 2.0 / 3.0)
+            info, st = dev.level_info(3), dev.level_storage(3)
+            assert info["symmetric_diagonals"] == 4 and st["distinct_rows"] > 255, (info, st)
+            if escape and case != "patch16":
+                assert info["row_classes"] == 255 and 0 < st["escape_rows"] <= 0.25 * n, (info, st)
+                if case != "scaled":
+                    # (all of the odd rows but those that were picked for the dictionary's spare classes)
+                    assert int(odd.sum()) - 254 <= st["escape_rows"] <= int(odd.sum())
+                assert dev.time_kernel("jacobik3", 3, 1) > 0.0                  # the march runs on this level
+            else:
+                assert info["row_classes"] == 0 and st["escape_rows"] == 0, (info, st)
+            for nw in (3, 4, 5, 7, 12):
+                dev.set_vector(3, "v", v_in)
+                dev.set_vector(3, "f", f_in)
+                dev.smooth(3, nw)
+                outs[escape, nw] = dev.get_vector(3, "v")
+            dev.set_vector(3, "f", bag.b_dict[3])
+            dev.zero_vector(3, "v")
+            outs[escape, "res"] = dev.vcycle(3, 3, residuals=True)
+    for nw in (3, 4, 5, 7, 12):
+        assert np.array_equal(outs[1, nw], outs[0, nw]), (case, nw)
+    assert np.all(np.abs(outs[1, "res"] - outs[0, "res"]) <= 1e-13 * outs[0, "res"])
+    want = jacobi_relaxation(get_jacobi_matrices((B, 3)), v_in, f_in, 5, 2.0 / 3.0)
+    assert rel_l2(outs[1, 5], want) <= 1e-13
+
+
 @pytest.mark.parametrize("c,lo,hi", [(8, 1, 4), (5, 1, 5), (3, 2, 6)])
 def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi):
     """mg_jacobi2.hip.h, sdia_jacobik2d: up to five Jacobi sweeps per launch on 2-D levels (tile region in LDS, the
@@ -1396,7 +1463,7 @@ def test_storage_ulps_brings_round_off_noisy_assemblies_to_the_compact_formats()
                 assert st["symmetric"] == 2 and st["ulps_used"] == (8 if ulps == 8 else 4) and 2 <= st["distinct_rows"] <= 255, st
             # (an exactly symmetric, repetitive level: nothing identified -- unless "storage_ulps" asks for the tolerance everywhere)
             assert dev.level_storage(2) == dict(symmetric=1, first_asymmetric_row=-1, max_pair_ulps=0, ulps_used=8 if ulps == 8 else 0,
-                                                distinct_rows=dev.level_info(2)["row_classes"] - 1)
+                                                distinct_rows=dev.level_info(2)["row_classes"] - 1, escape_rows=0)
             dev.set_vector(3, "v", v_in)
             dev.set_vector(3, "f", bag.b_dict[3])
             dev.smooth(3, 6)
