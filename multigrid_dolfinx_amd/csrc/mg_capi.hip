@@ -1319,6 +1319,8 @@ int escape_window_k(mg_context* c, const Level& L, const unsigned char* cls, int
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(most, a.most, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (std::getenv("MG_DEBUG_STORAGE"))
+        std::fprintf(stderr, "[mg] escape rows: at most %u in %d planes of a tile (%d sweeps per pass, pool of %d)\n", *most, K + 2, K, jk3_pool(K));
     return 0;
 }
 
@@ -2429,15 +2431,16 @@ int build_row_classes_q(mg_context* c, Level& L, int qbits) {
         rc = [&]() -> int {
             unsigned* slot_count = nullptr;
             struct Free { unsigned*& p; ~Free() { if (p) (void)hipFree(p); } } guard{slot_count};
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot_count), CLS_SLOTS * sizeof(unsigned)));
-            HIP_TRY(hipMemsetAsync(slot_count, 0, CLS_SLOTS * sizeof(unsigned), c->stream));
+            // (slot counts | one bit per hash value: seen once)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot_count), (CLS_SLOTS + CLS_SEEN_BITS / 32) * sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(slot_count, 0, (CLS_SLOTS + CLS_SEEN_BITS / 32) * sizeof(unsigned), c->stream));
             HIP_TRY(hipMemsetAsync(scratch.p, 0, tag_bytes + val_bytes + int_bytes, c->stream));
             const int64_t nsample = std::min<int64_t>(L.nloc, (int64_t)1 << 20);
             const dim3 sgrid(blocks_for(nsample, 256));
             switch (L.R) {
-                case 1: hipLaunchKernelGGL(cls_sample_insert<64>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
-                case 2: hipLaunchKernelGGL(cls_sample_insert<128>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
-                default: hipLaunchKernelGGL(cls_sample_insert<256>, sgrid, blk, 0, c->stream, a, nsample, slot_count); break;
+                case 1: hipLaunchKernelGGL(cls_sample_insert<64>, sgrid, blk, 0, c->stream, a, nsample, slot_count, slot_count + CLS_SLOTS); break;
+                case 2: hipLaunchKernelGGL(cls_sample_insert<128>, sgrid, blk, 0, c->stream, a, nsample, slot_count, slot_count + CLS_SLOTS); break;
+                default: hipLaunchKernelGGL(cls_sample_insert<256>, sgrid, blk, 0, c->stream, a, nsample, slot_count, slot_count + CLS_SLOTS); break;
             }
             HIP_TRY(hipGetLastError());
             std::vector<unsigned> cnt(CLS_SLOTS);
@@ -2474,6 +2477,9 @@ int build_row_classes_q(mg_context* c, Level& L, int qbits) {
             rc = escape_kmax(c, L, cls, cls_lead, &kmax);
             escape = !rc && kmax >= 3;
         }
+        if (std::getenv("MG_DEBUG_STORAGE"))
+            std::fprintf(stderr, "[mg] row dictionary with escape: %lld rows, tolerance %d bits, %u escape rows, sweeps per pass that fit %d, rc %d\n",
+                         (long long)L.nloc, qbits, hist[CLS_ESCAPE], kmax, rc);
         if (escape) { h[0] = 254; h[1] = 0; L.esc_kmax = kmax; L.rep_escape = hist[CLS_ESCAPE]; }
     }
     if (rc || h[0] > 255 || h[1]) {                 // too many distinct rows (or a hash collision): plain pass

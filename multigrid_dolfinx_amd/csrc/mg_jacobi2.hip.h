@@ -409,11 +409,14 @@ __global__ void cls_assign(ClsArgs a) {
 // ---- more than 255 distinct rows: the frequent rows as classes, the others "escape" to their stored row -----------------
 // (class CLS_ESCAPE: the K-sweep march reads such a row from the symmetric diagonal storage; the other class kernels leave
 // a level with escapes alone.)  Which rows are frequent is found on a SAMPLE spread over the level -- a row that occurs with
-// frequency p is in the table after ~1/p samples, long before rare rows have filled it --, with an occurrence count per slot.
+// frequency p is in the table after ~1/p samples --, with an occurrence count per slot.  A row enters the table when it is
+// seen for the SECOND time (a bit per hash value remembers the first): rows that occur once in the sample -- the odd ones,
+// of which a level may have millions -- never get there, so they cannot crowd the frequent rows out.
 constexpr int CLS_ESCAPE = 255;
+constexpr int CLS_SEEN_BITS = 1 << 22;
 
 template <int S>
-__global__ void cls_sample_insert(ClsArgs a, int64_t nsample, unsigned* slot_count) {
+__global__ void cls_sample_insert(ClsArgs a, int64_t nsample, unsigned* slot_count, unsigned* seen_bits) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nsample) return;
     const int64_t row = (int64_t)(((unsigned long long)t * 0x9e3779b97f4a7c15ull >> 11) % (unsigned long long)a.nloc);
@@ -422,11 +425,18 @@ __global__ void cls_sample_insert(ClsArgs a, int64_t nsample, unsigned* slot_cou
     if (cls_zero(b)) return;
     const unsigned long long h = cls_hash(b, a.qbits);
     unsigned s = (unsigned)h & (CLS_SLOTS - 1);
+    bool marked = false;        // this row's first sighting has been dealt with
     for (int probe = 0; probe < CLS_SLOTS; ++probe) {
-        const unsigned long long seen = *(volatile unsigned long long*)(a.tags + s);
-        if (seen == h) { atomicAdd(slot_count + s, 1u); return; }
-        if (seen != 0ull) { s = (s + 1) & (CLS_SLOTS - 1); continue; }
-        if (*(volatile int*)a.count >= (CLS_SLOTS * 3) / 4) return;           // table as full as it gets: a rare row
+        const unsigned long long tag = *(volatile unsigned long long*)(a.tags + s);
+        if (tag == h) { atomicAdd(slot_count + s, 1u); return; }
+        if (tag != 0ull) { s = (s + 1) & (CLS_SLOTS - 1); continue; }
+        // not in the table (yet)
+        if (!marked) {
+            const unsigned bit = (unsigned)(h >> 32) & (CLS_SEEN_BITS - 1), mask = 1u << (bit & 31);
+            if (!(atomicOr(seen_bits + (bit >> 5), mask) & mask)) return;       // the first sighting only leaves its mark
+            marked = true;
+        }
+        if (*(volatile int*)a.count >= (CLS_SLOTS * 3) / 4) return;           // table as full as it gets
         const unsigned long long old = atomicCAS(a.tags + s, 0ull, h);
         if (old == 0ull) {
 #pragma unroll

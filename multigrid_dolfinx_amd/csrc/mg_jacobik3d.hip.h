@@ -193,6 +193,14 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
         shw |= (r < 0 ? 0u : (r >= a.P ? 2u : 1u)) << (2 * c);
     }
     auto shof = [&](int c) -> int { return (int)((shw >> (2 * c)) & 3u) - 1; };
+    // (ESC) bit c: cell c is a stand-in -- its line or its place in the line is clamped (see `eo`), it reads another cell's
+    // row and no result depends on it: if that row is an escape row, the cell goes on as class 0 and takes no pool row
+    unsigned standin = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int line = ty0 + ey0 + c / M;
+        if (lane + 64 * (c % M) > a.nx + 1 - tx0 || line < -2 || line > a.ny + 1) standin |= 1u << c;
+    }
     const bool wlo = wave == 0, whi = wave == NW - 1;
 
     // Addresses: `uniform base of the plane + a byte offset fixed for the whole march` (see j2c_body).  Lines are
@@ -470,6 +478,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
                 auto at = [&](int64_t m, int slot) -> double { return dv[((((m >> sh) << 2) + slot) << sh) + (m & (((int64_t)1 << sh) - 1))]; };
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
+                    if (C[c] == CLS_ESCAPE && (standin >> c & 1u)) C[c] = 0;
                     const unsigned long long em = __ballot(C[c] == CLS_ESCAPE);
                     if (em != 0ull) {
                         unsigned b0 = 0u;
@@ -607,7 +616,7 @@ void sdia_jacobikc_escape(JK3Args a) {
 
 // The most pool rows any tile of the march <K, NW, LPW, M> takes within K + 2 consecutive planes: one workgroup per tile
 // counts the cells of class CLS_ESCAPE plane by plane -- the tile's cells at the very rows the march reads their classes
-// from (clamped like its byte offsets `eo`) -- and keeps the largest sum over a window of planes.
+// from, but for the clamped ones (`standin` there) -- and keeps the largest sum over a window of planes.
 struct JK3WindowArgs {
     const unsigned char* cls;
     int64_t clead, P;
@@ -627,8 +636,9 @@ __global__ __launch_bounds__(256) void jk3_escape_window(JK3WindowArgs a) {
         __syncthreads();
         unsigned n = 0u;
         for (int i = threadIdx.x; i < EX * EY; i += 256) {
-            const int ex = i % EX, ey = i / EX;
-            const int64_t row = (int64_t)p * a.P + (int64_t)min(max(ty0 + ey, -2), a.ny + 1) * a.nx + tx0 + min(ex, xcl);
+            const int ex = i % EX, line = ty0 + i / EX;
+            if (ex > xcl || line < -2 || line > a.ny + 1) continue;
+            const int64_t row = (int64_t)p * a.P + (int64_t)line * a.nx + tx0 + ex;
             n += a.cls[a.clead + row] == CLS_ESCAPE ? 1u : 0u;
         }
         if (n) atomicAdd(&s_plane, n);

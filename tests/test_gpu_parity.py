@@ -1364,8 +1364,9 @@ def test_escape_rows_keep_the_class_path(case):
             if escape and case != "patch16":
                 assert info["row_classes"] == 255 and 0 < st["escape_rows"] <= 0.25 * n, (info, st)
                 if case != "scaled":
-                    # (all of the odd rows but those that were picked for the dictionary's spare classes)
-                    assert int(odd.sum()) - 254 <= st["escape_rows"] <= int(odd.sum())
+                    # (the odd rows -- but for any that were picked for the dictionary's spare classes -- and the few regular rows
+                    #  that the dictionary's sample met only once: rows next to a corner of the grid)
+                    assert int(odd.sum()) - 254 <= st["escape_rows"] <= int(odd.sum()) + 64
                 assert dev.time_kernel("jacobik3", 3, 1) > 0.0                  # the march runs on this level
             else:
                 assert info["row_classes"] == 0 and st["escape_rows"] == 0, (info, st)
