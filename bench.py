@@ -89,6 +89,7 @@ def parse():
                          "(debugging on a box with fewer GPUs than ranks; slow, never a headline number)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-odd-rows", action="store_true", help="skip the extra hierarchy with 1 %% odd rows (value_with_odd_rows)")
     ap.add_argument("--cpu-sample-level", type=int, default=4, help="finest level of the CPU sample (N = 8*2^l)")
     return ap.parse_args()
 
@@ -508,6 +509,19 @@ def main():
     dev = h.device_info()
     h.close()
 
+    # ... and the rate a level with a FEW rows unlike any other gets ("row_escape": the frequent rows keep their classes, the
+    # odd ones are fetched from the stored matrix inside the K-sweep pass): the same hierarchy generated with 1 % of the
+    # interior rows carrying a reaction term of their own ("gen_odd_rows"), one rank, the headline configuration only
+    odd_rows = None
+    if args.config == "c4" and args.gpus == 1 and has_classes and not user_tuning and not args.no_odd_rows:
+        from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
+        with DeviceHierarchy.synthetic(dim, lo, hi, c=8, mu1=args.mu, mu2=args.mu, omega=args.omega, gen_odd_rows=100) as ho:
+            st = ho.level_storage(hi)
+            k_odd = max(1, min(args.steps, 3))
+            odd_rows = {"share": 0.01, "escape_rows": st["escape_rows"], "row_classes": ho.level_info(hi)["row_classes"],
+                        "value": k_odd / timed_cycles(ho, rv, hi, 1, k_odd),
+                        "note": "same V-cycles on a hierarchy whose levels have 1 % rows unlike any other (more than 255 distinct rows)"}
+
     out = None
     if rv.rank == 0:
         per_s = args.steps / elapsed
@@ -561,6 +575,7 @@ def main():
                          "csr_model_bytes_per_launch": csr_model_bytes,
                          "speedup_vs_csr_model": csr_model_bytes / bytes_launch},
             "value_without_row_classes": value_plain,
+            "value_with_odd_rows": odd_rows,
             "v22_cycles_per_s": v22_per_s, "residual_l2_after": res_after, "rhs_l2": f_norm,
             "setup_s": t_setup, "device_memory_GB_per_gpu": mem / 1e9, "device": dev,
         }

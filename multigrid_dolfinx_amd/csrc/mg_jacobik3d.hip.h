@@ -476,25 +476,40 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
                 const int sh = a.sshift;
                 const double* const dv = a.dvals;
                 auto at = [&](int64_t m, int slot) -> double { return dv[((((m >> sh) << 2) + slot) << sh) + (m & (((int64_t)1 << sh) - 1))]; };
+                // (one counter update per wave and plane; the loads of all its cells in flight together)
+                unsigned long long em[NC];
+                unsigned total = 0u;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if (C[c] == CLS_ESCAPE && (standin >> c & 1u)) C[c] = 0;
-                    const unsigned long long em = __ballot(C[c] == CLS_ESCAPE);
-                    if (em != 0ull) {
-                        unsigned b0 = 0u;
-                        if (lane == 0) b0 = atomicAdd(esc_count, (unsigned)__popcll(em));
-                        b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                    em[c] = __ballot(C[c] == CLS_ESCAPE);
+                    total += (unsigned)__popcll(em[c]);
+                }
+                if (total != 0u) {
+                    unsigned b0 = 0u;
+                    if (lane == 0) b0 = atomicAdd(esc_count, total);
+                    b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                    double e[NC][7];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
                         if (C[c] == CLS_ESCAPE) {
-                            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
-                            const int row = DYN0 + (int)((b0 + below) & (unsigned)(jk3_pool(K) - 1));
                             const int64_t m = mp + (int64_t)(eo[c] >> 3);
-                            const double e0 = at(m - a.P, 3), e1 = at(m - a.nx, 2), e2 = at(m - 1, 1);
-                            const double e3 = at(m, 0), e4 = at(m, 1), e5 = at(m, 2), e6 = at(m, 3);
+                            e[c][0] = at(m - a.P, 3); e[c][1] = at(m - a.nx, 2); e[c][2] = at(m - 1, 1);
+                            e[c][3] = at(m, 0); e[c][4] = at(m, 1); e[c][5] = at(m, 2); e[c][6] = at(m, 3);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (C[c] == CLS_ESCAPE) {
+                            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(em[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em[c], 0u));
+                            const int row = DYN0 + (int)((b0 + below) & (unsigned)(jk3_pool(K) - 1));
                             double* const tr = sT + CLS_W * row;
-                            tr[0] = e0; tr[1] = e1; tr[2] = e2; tr[3] = e3; tr[4] = e4; tr[5] = e5; tr[6] = e6;
-                            tr[7] = a.omega * (1.0 / (e3 != 0.0 ? e3 : 1.0));
+#pragma unroll
+                            for (int i = 0; i < 7; ++i) tr[i] = e[c][i];
+                            tr[7] = a.omega * (1.0 / (e[c][3] != 0.0 ? e[c][3] : 1.0));
                             C[c] = row;
                         }
+                        b0 += (unsigned)__popcll(em[c]);
                     }
                 }
             }
