@@ -18,7 +18,7 @@ echo "trace"; rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TA
     > "$OUT/${TAG}_c4_bench_under_rocprof.json" 2> "$OUT/${TAG}_c4_bench.err"
 python3 "$R/profiles/summarize.py" trace "$OUT/${TAG}_c4_trace" "$OUT/${TAG}_c4_kernel_by_grid.csv"
 cp "$(ls "$OUT/${TAG}_c4_trace"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_c4_kernel_stats.csv"
-SHORT="--steps 1 --warmup 0 --mu 1 --kernel-reps 2 --no-cpu-baseline"
+SHORT="--steps 1 --warmup 0 --mu 1 --kernel-reps 2 --no-cpu-baseline --no-odd-rows"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   N=$(echo $C | cut -d' ' -f1 | tr 'A-Z' 'a-z' | sed 's/_size//; s/tcc_hit_sum/l2/')
   echo "pmc $N"
