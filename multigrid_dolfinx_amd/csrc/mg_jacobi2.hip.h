@@ -494,6 +494,12 @@ __global__ __launch_bounds__(256) void cls_encode_escape(ClsArgs a) {
 
 template <int S>
 __global__ __launch_bounds__(256) void cls_encode(ClsArgs a) {
+    // (more than 255 distinct rows: the insert pass may have filled the table to the brim before its threads saw the count, and a
+    //  row that is not in a full table walks all of it -- seconds on a level of 10^9 rows; the caller discards the encoding anyway)
+    if (*a.count > 255) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.flag = 1;
+        return;
+    }
     __shared__ unsigned s_hist[256];
     s_hist[threadIdx.x] = 0u;
     __syncthreads();

@@ -35,6 +35,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r["achieved"] - r["format_bytes_per_row"] * r["rows_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.9
     assert "speedup_vs_csr_model" in r and "value_without_row_classes" in d
+    assert "value_with_odd_rows" in d and d["value_with_odd_rows"] is None         # (measured on the headline configuration only)
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
