@@ -47,7 +47,7 @@ def kernel_source_sha():
     import hashlib
     hsh = hashlib.sha256()
     base = os.path.join(ROOT, "multigrid_dolfinx_amd", "csrc")
-    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_jacobik3d.hip.h", "mg_lattice.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
+    for name in ("mg_kernels.hip.h", "mg_jacobi2.hip.h", "mg_jacobik3d.hip.h", "mg_jacobiblk.hip.h", "mg_lattice.hip.h", "mg_direct.hip.h", "mg_capi.hip"):
         try:
             hsh.update(open(os.path.join(base, name), "rb").read())
         except OSError:

@@ -199,6 +199,16 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          to reach the compact formats: 2.6 x on the headline pass); the perturbation -- at most 4 ulps per
  *                          entry, below the assembly's own round-off -- is reported by mg_level_storage.  0 = exact storage
  *                          only (1)
+ *     "fuse_block"         1 = whole seven-point levels with row classes of "fuse_block_min_rows" <= rows < "fuse_block_max_rows" --
+ *                          the middle levels, too small for the plane marches -- are relaxed K sweeps per launch on blocks of
+ *                          32 x 32 x EZ cells that stay on the CU (mg_jacobiblk.hip.h), each block recomputing a halo of K
+ *                          cells; bit-identical to single sweeps.  2 = whatever the level's size (tests), 0 = off.  Off by default: measured no
+ *                          faster than one launch per sweep (0)
+ *     "fuse_block_min_rows"  see "fuse_block" (2^15)
+ *     "fuse_block_max_rows"  see "fuse_block" (2^23)
+ *     "fuse_block_k"       sweeps per launch of the block pass, 2..4; 0 = chosen by a cost model (rounds of workgroups x planes
+ *                          loaded and relaxed per cell kept) (0)
+ *     "fuse_block_ez"      planes per block of the block pass, 11 or 19; 0 = chosen likewise (0)
  *     "gen_odd_rows"       mg_gen_poisson_level gives this many of 10000 interior rows, picked by a hash of their grid index, a
  *                          reaction term of their own on the diagonal (a.diag * (1 + r), 0 <= r < 1): rows unlike any other,
  *                          for measuring what "row_escape" costs.  Levels generated afterwards (0)
@@ -397,6 +407,8 @@ int mg_counters(mg_handle h, int64_t* uploads, int64_t* downloads, int64_t* grap
  * error on levels where mg_smooth does not use it; "jacobi2!" = the same wherever the kernel applies;
  * "jacobi_small" = the mu1 sweeps of a small level in one launch, an error where mg_smooth does not do that;
  * "jacobik" = one launch of the K-sweep 2-D kernel with K = "fuse_2d_k", an error on levels that do not use it;
+ * "jacobik3" = one launch of the K-sweep plane march on a 3-D level ("jacobik3!": wherever it applies), "jacobiblk" = one launch
+ * of the block pass ("fuse_block"; "jacobiblk!": whatever the level's size), errors on levels that do not use them;
  * "gs" = one full Gauss-Seidel sweep, all colours, with the configured Gauss-Seidel smoother).
  * Used by bench.py for the roofline figure.  mg_sync waits for the handle's stream. */
 int mg_time_kernel(mg_handle h, const char* kernel, int level, int reps, double* avg_ms);

@@ -6,6 +6,7 @@
 #include "mg_direct.hip.h"
 #include "mg_jacobi2.hip.h"
 #include "mg_jacobik3d.hip.h"
+#include "mg_jacobiblk.hip.h"
 #include "mg_lattice.hip.h"
 
 #include <dlfcn.h>
@@ -134,6 +135,7 @@ struct Level {
     int rep_sym = -1, rep_sym_qbits = 0, rep_cls_qbits = 0, rep_distinct = -1;
     int64_t rep_first_asym = -1, rep_max_ulps = 0;
     bool cls_escape = false;     // rows of class CLS_ESCAPE exist: read from the stored row (K-sweep march only; other class kernels off)
+    bool grid_decoupled = false; // no entry couples cells that are no grid neighbours (sdia_grid_decoupled; levels with row classes)
     int esc_kmax = 0;            // ... and the most sweeps per pass whose tiles' escape rows fit the march's pool (jk3_escape_window)
     int64_t rep_escape = 0;      // ... how many
     int cls_halo = 0;            // row classes of the neighbours' planes next to this slab: 0 not built yet, 1 in place, -1 unavailable
@@ -256,6 +258,13 @@ struct mg_context {
     int use_direct = 1;             // exact block-tridiagonal coarsest solve where the level allows it
     int require_diagonal = 1;       // 0: operators without a diagonal (D^-1 R of the split smoother)
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
+    // K sweeps per launch on blocks resident on the CU (mg_jacobiblk.hip.h): whole 3-D levels with row classes of
+    // fuse_block_min_rows <= rows < fuse_block_max_rows (below the plane marches' sizes); 2: whatever the size (tests).
+    // OFF: measured no faster than one launch per sweep (129^3: 13.2 us per sweep against 14.3; 65^3: 3.4 against 4.0;
+    // profiles/r03_block_pass.txt) -- the blocks' recomputed halos (x 2.2 cells) make the pass VALU-bound
+    int fuse_block = 0;
+    int64_t fuse_block_min_rows = (int64_t)1 << 15, fuse_block_max_rows = (int64_t)1 << 23;
+    int fuse_block_k = 0, fuse_block_ez = 0;    // 0: chosen by the cost model; else 2..4 sweeps per launch / blocks of 11 or 19 planes
     int gen_odd_rows = 0;           // "gen_odd_rows": mg_gen_poisson_level perturbs the diagonal of this many interior rows in 10000
     int cls_escape = 1;             // "row_escape": more than 255 distinct rows -> the frequent ones as classes, the rest read from their stored row
     int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 4 ulps
@@ -498,7 +507,7 @@ void free_level(mg_context* c, Level& L) {
     dev_free(c, L.cls, (size_t)L.cls_rows);
     dev_free(c, L.ctab, 256 * CLS_W);
     L.ncls = 0;
-    L.cls_escape = false; L.esc_kmax = 0; L.rep_escape = 0;
+    L.cls_escape = false; L.esc_kmax = 0; L.rep_escape = 0; L.grid_decoupled = false;
     L.cls_halo = 0;
     L.rep_sym = -1; L.rep_sym_qbits = L.rep_cls_qbits = 0; L.rep_distinct = -1; L.rep_first_asym = -1; L.rep_max_ulps = 0;
     dev_free(c, L.scls, (size_t)L.nslices * WAVE * L.R);
@@ -1591,6 +1600,69 @@ int launch_sweep1c(mg_context* c, const Level& L, int mode, const double* x_rows
 
 // All sweeps of a small level in one launch (mg_jacobi2.hip.h, sdia_jacobi_small): whole five- / seven-point levels with
 // row classes that fit one CU's LDS.
+// K sweeps per launch on blocks resident on the CU (mg_jacobiblk.hip.h): whole seven-point levels with row classes, sizes
+// below the plane marches'
+bool block_sweeps_ok(const mg_context* c, const Level& L) {
+    if (!c->fuse_block || !L.sdia || L.wu != 4 || !cls_full(L) || !c->fuse_classes || L.flat || !L.replicated) return false;
+    if (!L.grid_decoupled || L.ncls > 128 || L.g.nx < 8 || L.g.ny < 8 || L.g.nk < 8 || L.nloc >= ((int64_t)1 << 28)) return false;
+    return c->fuse_block >= 2 || (L.nloc >= c->fuse_block_min_rows && L.nloc < c->fuse_block_max_rows);
+}
+
+// sweeps per launch and planes per block: the launch runs in rounds of one workgroup per CU, a workgroup loads EZ planes
+// of 32 x 32 cells (about 0.33 us per plane) and relaxes them K times (0.13 us per plane and sweep), of which it keeps
+// (32 - 2K)^2 (EZ - 2K) cells
+struct JBPlan { int K, EZ; };
+
+JBPlan block_plan(const mg_context* c, const Level& L) {
+    JBPlan best{3, 19};
+    double best_cost = 1e300;
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    for (int K = 2; K <= 4; ++K)
+        for (int EZ : {11, 19}) {
+            if (c->fuse_block_k && K != c->fuse_block_k) continue;
+            if (c->fuse_block_ez && EZ != c->fuse_block_ez) continue;
+            const int ow = JB_E - 2 * K, oz = EZ - 2 * K;
+            const int64_t nb = (int64_t)((L.g.nx + ow - 1) / ow) * ((L.g.ny + ow - 1) / ow) * ((L.g.nk + oz - 1) / oz);
+            const double cost = (double)((nb + cus - 1) / cus) * EZ * (0.33 + 0.13 * K) / K;
+            if (cost < best_cost) { best_cost = cost; best = JBPlan{K, EZ}; }
+        }
+    return best;
+}
+
+template <int K, int EZ>
+int launch_jacobi_block_t(mg_context* c, const Level& L, JBArgs a) {
+    constexpr int ow = JB_E - 2 * K, oz = EZ - 2 * K;
+    a.nbx = (a.nx + ow - 1) / ow;
+    a.nby = (a.ny + ow - 1) / ow;
+    const int64_t nb = (int64_t)a.nbx * a.nby * ((a.nz + oz - 1) / oz);
+    if (nb >= ((int64_t)1 << 31)) return fail("too many blocks");
+    const size_t lds = jb_lds_bytes<EZ>(a.ncls);
+    if (lds > (size_t)160 * 1024) return fail("block pass: class table too large");
+    void (*const kern)(JBArgs) = sdia_jacobi_block<K, EZ>;
+    MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)160 * 1024));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out = K Jacobi sweeps applied to x (2 <= K <= 4), blocks of EZ planes (11 or 19)
+int launch_jacobi_block(mg_context* c, const Level& L, int K, int EZ, const double* x_rows, const double* f_rows, double* out_rows) {
+    JBArgs a{};
+    a.x = x_rows; a.f = f_rows; a.out = out_rows;
+    a.cls = L.cls + L.cls_lead; a.ctab = L.ctab; a.ncls = L.ncls; a.cmain = L.cmain;
+    for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
+    a.omega = c->omega; a.nx = L.g.nx; a.ny = L.g.ny; a.nz = L.g.nk; a.P = L.g.plane;
+    switch (K * 100 + EZ) {
+        case 211: return launch_jacobi_block_t<2, 11>(c, L, a);
+        case 219: return launch_jacobi_block_t<2, 19>(c, L, a);
+        case 311: return launch_jacobi_block_t<3, 11>(c, L, a);
+        case 319: return launch_jacobi_block_t<3, 19>(c, L, a);
+        case 411: return launch_jacobi_block_t<4, 11>(c, L, a);
+        case 419: return launch_jacobi_block_t<4, 19>(c, L, a);
+        default: return fail("block pass: 2..4 sweeps per launch on blocks of 11 or 19 planes");
+    }
+}
+
 bool small_level_ok(const mg_context* c, const Level& L) {
     if (!c->fuse_small || !L.sdia || !cls_full(L) || !c->fuse_classes || L.flat || !L.replicated) return false;
     if (L.wu != 3 && L.wu != 4) return false;
@@ -1657,6 +1729,19 @@ int smooth(mg_context* c, int level, int nw) {
         MG_TRY(launch_jacobi_small(c, L, nw, L.v.rows, L.f.rows, L.v2.rows));
         std::swap(L.v, L.v2);
         return 0;
+    }
+    if (!dist && nw >= 2 && block_sweeps_ok(c, L)) {
+        // middle 3-D levels: K sweeps per launch on blocks resident on the CU, the rest (at most one) as a single sweep
+        const JBPlan plan = block_plan(c, L);
+        int left = nw;
+        while (left >= 2) {
+            int k = std::min(plan.K, left);
+            if (left - k == 1 && k > 2) --k;                // 4 = 2 + 2 rather than 3 + 1
+            MG_TRY(launch_jacobi_block(c, L, k, plan.EZ, L.v.rows, L.f.rows, L.v2.rows));
+            std::swap(L.v, L.v2);
+            left -= k;
+        }
+        nw = left;
     }
     if (!dist && sweeps2d_ok(c, L)) {
         // 2-D levels: up to fuse_2d_k sweeps per launch, the rest (at most one) as a single sweep
@@ -2494,6 +2579,19 @@ int build_row_classes_q(mg_context* c, Level& L, int qbits) {
     for (int k = 1; k < L.ncls; ++k)
         if (L.cmain == 0 || hist[k] > hist[L.cmain]) L.cmain = k;
     for (int t = 0; t < 8; ++t) L.cm[t] = tab[(size_t)CLS_W * L.cmain + t];
+    // what the block pass (mg_jacobiblk.hip.h) needs to know: blocks are cut in grid coordinates
+    if (L.wu == 4 && !L.cls_escape && !L.flat && L.up[1] == 1 && L.up[2] == L.g.nx && (int64_t)L.up[3] == L.g.plane) {
+        JBCheckArgs k{};
+        k.cls = L.cls + L.cls_lead; k.ctab = L.ctab; k.nx = L.g.nx; k.ny = L.g.ny; k.nz = L.g.nk; k.P = L.g.plane; k.n = L.nloc;
+        k.flag = reinterpret_cast<int*>(c->partials);
+        HIP_TRY(hipMemsetAsync(k.flag, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(sdia_grid_decoupled, dim3(blocks_for(L.nloc, 256)), dim3(256), 0, c->stream, k);
+        HIP_TRY(hipGetLastError());
+        int flag = 1;
+        HIP_TRY(hipMemcpyAsync(&flag, k.flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        L.grid_decoupled = flag == 0;
+    }
     return 0;
 }
 
@@ -2990,6 +3088,19 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         int q = 0;
         while ((1ll << q) < value) ++q;
         c->storage_qbits = value > 0 ? std::max(1, q) : 0;
+    } else if (k == "fuse_block") {
+        if (value < 0 || value > 2) return fail("fuse_block must be 0, 1 or 2");
+        c->fuse_block = (int)value;
+    } else if (k == "fuse_block_min_rows") {
+        c->fuse_block_min_rows = value;
+    } else if (k == "fuse_block_max_rows") {
+        c->fuse_block_max_rows = value;
+    } else if (k == "fuse_block_k") {
+        if (value != 0 && (value < 2 || value > 4)) return fail("fuse_block_k must be 0 or 2..4");
+        c->fuse_block_k = (int)value;
+    } else if (k == "fuse_block_ez") {
+        if (value != 0 && value != 11 && value != 19) return fail("fuse_block_ez must be 0, 11 or 19");
+        c->fuse_block_ez = (int)value;
     } else if (k == "gen_odd_rows") {
         if (value < 0 || value > 10000) return fail("gen_odd_rows: rows in 10000");
         c->gen_odd_rows = (int)value;
@@ -3908,6 +4019,15 @@ int mg_time_kernel(mg_handle c, const char* kernel, int level, int reps, double*
             const int rc = launch_jacobikc(c, L, slab ? std::min(std::min(c->fuse_k, 5), L.hd) : sweepsk_max(c, L), L.v.rows, L.f.rows, L.v2.rows);
             c->timing_force_form = -1;
             return rc;
+        }
+        if (k == "jacobiblk" || k == "jacobiblk!") {      // K sweeps per launch on resident blocks ("!": whatever the level's size)
+            const int keep = c->fuse_block;
+            if (k.back() == '!') c->fuse_block = 2;
+            const bool ok = block_sweeps_ok(c, L);
+            c->fuse_block = keep;
+            if (!ok) return fail("level does not use the block pass");
+            const JBPlan plan = block_plan(c, L);
+            return launch_jacobi_block(c, L, plan.K, plan.EZ, L.v.rows, L.f.rows, L.v2.rows);
         }
         if (k == "jacobi_small") {           // all mu1 sweeps of a small level in one launch
             if (!small_level_ok(c, L) || c->mu1 < 2) return fail("level does not use the one-launch smoother");

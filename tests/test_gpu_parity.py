@@ -1234,7 +1234,11 @@ def test_two_sweep_kernel_is_bit_identical_to_single_sweeps(c, lo, hi):
                 # (the tiles of a last, nearly empty round in shorter segments: planned for 4 / 5 / 7 resident workgroups so
                 #  that these few-tile grids have such a tail; 0: every tile alike)
                 dict(fuse_k=5, fuse_k_tail=4), dict(fuse_k=4, fuse_k_tail=5, fuse_k_shape=1), dict(fuse_k=3, fuse_k_tail=7),
-                dict(fuse_k=5, fuse_k_tail=0)]
+                dict(fuse_k=5, fuse_k_tail=0),
+                # (the block pass of mg_jacobiblk.hip.h on every level, in all its shapes: K sweeps per launch, planes per block)
+                dict(fuse_block=2), dict(fuse_block=2, fuse_block_k=2, fuse_block_ez=11), dict(fuse_block=2, fuse_block_k=3, fuse_block_ez=11),
+                dict(fuse_block=2, fuse_block_k=4, fuse_block_ez=11), dict(fuse_block=2, fuse_block_k=2, fuse_block_ez=19),
+                dict(fuse_block=2, fuse_block_k=3, fuse_block_ez=19), dict(fuse_block=2, fuse_block_k=4, fuse_block_ez=19)]
     for kw in variants:
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
