@@ -391,6 +391,7 @@ def main():
     try:        # the smoother runs K sweeps per pass on this level (mg_jacobik3d.hip.h): that launch is the dominant one
         pair_ms = h.time_kernel("jacobik3", hi, args.kernel_reps)
         multi_k = march_k = min(tuned.get("fuse_k", 5), 3 if info["n_local"] < tuned.get("fuse_k4_min_rows", 0) else
+                                5 if info["n_local"] < tuned.get("fuse_k_small_rows", 1 << 22) else
                                 4 if info["n_local"] < tuned.get("fuse_k5_min_rows", 1 << 26) else 5)
     except Exception:
         pair_ms = None

@@ -209,6 +209,10 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_block_k"       sweeps per launch of the block pass, 2..4; 0 = chosen by a cost model (rounds of workgroups x planes
  *                          loaded and relaxed per cell kept) (0)
  *     "fuse_block_ez"      planes per block of the block pass, 11 or 19; 0 = chosen likewise (0)
+ *     "direct_block_rows"  the coarsest level's exact solve (block-tridiagonal LU over groups of grid planes / lines) takes blocks
+ *                          of at least this many rows, at most 2304: a solve is three dependent launches per block, so fewer,
+ *                          larger blocks are faster while their dense inverses (rows^2 x 8 B each) stay small.  Before the first
+ *                          cycle (2048)
  *     "gen_odd_rows"       mg_gen_poisson_level gives this many of 10000 interior rows, picked by a hash of their grid index, a
  *                          reaction term of their own on the diagonal (a.diag * (1 + r), 0 <= r < 1): rows unlike any other,
  *                          for measuring what "row_escape" costs.  Levels generated afterwards (0)
@@ -253,7 +257,11 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_k_segments"    plane segments per tile of that march, 0 = chosen by its cost model (0)
  *     "fuse_k_slab_min_rows"  ... on slabs (below): levels whose smallest slab has at least this many rows (1048576)
  *     "fuse_k_slab_min_sweeps"  ... and smoother calls of at least this many sweeps (4)
- *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep the pairs (16777216)
+ *     "fuse_k_min_rows"    ... on whole levels with at least this many rows; smaller levels keep single sweeps (16777216: with
+ *                          2097152 the 129^3 level takes the march too -- 12.2 us per sweep against 14.3 alone, but whole cycles
+ *                          of BASELINE config 3 are no faster; 65^3 rows: 11.6 against 4.0)
+ *     "fuse_k_small_rows"  ... five sweeps per pass again on levels with fewer rows than this (4194304: 129^3 rows, 12.2 us per
+ *                          sweep with five against 15.5 with four)
  *     "fuse_k4_min_rows"   ... more than three sweeps per pass only on levels with at least this many rows (0)
  *     "fuse_k5_min_rows"   ... more than four only on levels with at least this many rows (67108864: on 257^3 rows four
  *                          sweeps per pass measured best)

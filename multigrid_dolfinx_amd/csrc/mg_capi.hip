@@ -265,6 +265,7 @@ struct mg_context {
     int fuse_block = 0;
     int64_t fuse_block_min_rows = (int64_t)1 << 15, fuse_block_max_rows = (int64_t)1 << 23;
     int fuse_block_k = 0, fuse_block_ez = 0;    // 0: chosen by the cost model; else 2..4 sweeps per launch / blocks of 11 or 19 planes
+    int direct_block_rows = 2048;   // "direct_block_rows": rows per block of the coarsest level's block-tridiagonal LU, at least
     int gen_odd_rows = 0;           // "gen_odd_rows": mg_gen_poisson_level perturbs the diagonal of this many interior rows in 10000
     int cls_escape = 1;             // "row_escape": more than 255 distinct rows -> the frequent ones as classes, the rest read from their stored row
     int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 4 ulps
@@ -287,7 +288,11 @@ struct mg_context {
                                     // each form is by itself)
     int64_t fuse_k_slab_min_rows = (int64_t)1 << 20;   // ... on slabs: levels whose smallest slab has at least this many rows
     int fuse_k_slab_min_sweeps = 4; // ... on slabs: smoother calls of at least this many sweeps (fewer: pairs with the boundary chain)
-    int64_t fuse_k_min_rows = (int64_t)1 << 24;        // ... on whole levels with at least this many rows (fewer: pairs)
+    int64_t fuse_k_min_rows = (int64_t)1 << 24;        // ... on whole levels with at least this many rows (fewer: single sweeps.  129^3 rows:
+                                                       //     12.2 us per sweep in the march against 14.3 alone, but whole C3 cycles do not
+                                                       //     get faster with it, 127.4 against 127.9 per second; 65^3: 11.6 against 4.0)
+    int64_t fuse_k_small_rows = (int64_t)1 << 22;      // ... five sweeps per pass again on levels with fewer rows than this (129^3: 12.2 us
+                                                       //     per sweep with five, 15.5 with four: profiles/r03_small_levels.txt)
     int64_t fuse_k5_min_rows = (int64_t)1 << 26;       // ... five sweeps per pass on levels with at least this many rows (257^3: four measured best)
     int64_t fuse_k4_min_rows = 0;                      // ... more than three sweeps per pass on levels with at least this many rows
     int fuse_k_nt_store = 0;        // ... non-temporal stores of its result (experiment)
@@ -1305,13 +1310,14 @@ bool sweepsk_ok(const mg_context* c, const Level& L, bool ignore_size = false) {
     const bool slab = !L.replicated && c->comm.active();
     if (slab && (L.hd < 2 || L.cls_halo < 0 || c->halo_planes != 1)) return false;
     if (!ignore_size && (slab ? min_slab_rows(L) < c->fuse_k_slab_min_rows : L.nloc < c->fuse_k_min_rows)) return false;
-    return fused_sweeps_ok(c, L, ignore_size || slab) && L.g.nk >= 8;
+    // (the size test of the K-sweep pass is the one above: "fuse_min_rows" is the pair pass's)
+    return fused_sweeps_ok(c, L, true) && L.g.nk >= 8;
 }
 
 // sweeps per pass on a whole level (with the 64 x 32 tiles of 16 waves five sweeps per pass measured best on 1025^3 and 513^3
 // rows, four on 257^3, profiles/r03_ksweep_levels.txt; "fuse_k4_min_rows" caps smaller levels at three)
 int sweepsk_max(const mg_context* c, const Level& L) {
-    const int k = std::min(std::min(c->fuse_k, 5), L.nloc < c->fuse_k4_min_rows ? 3 : L.nloc < c->fuse_k5_min_rows ? 4 : 5);
+    const int k = std::min(std::min(c->fuse_k, 5), L.nloc < c->fuse_k4_min_rows ? 3 : L.nloc < c->fuse_k_small_rows ? 5 : L.nloc < c->fuse_k5_min_rows ? 4 : 5);
     return L.cls_escape ? std::min(k, L.esc_kmax) : k;
 }
 
@@ -1820,7 +1826,7 @@ int smooth(mg_context* c, int level, int nw) {
             nw = left;
         }
     }
-    if (!dist && (fused || L.cls_escape) && nw >= 3 && sweepsk_ok(c, L)) {
+    if (!dist && nw >= 3 && sweepsk_ok(c, L)) {
         // whole levels: K sweeps per pass while that leaves no single sweep over (50 = 12 x 4 + 2, 7 = 4 + 3, 5 = 3 + 2)
         const int kmax = sweepsk_max(c, L);
         int left = nw;
@@ -2084,15 +2090,17 @@ int build_direct(mg_context* c) {
     if (!c->use_direct || L.flat || L.g.lead != 0) return 0;
     const int64_t plane = L.g.plane;
     const int nz = L.g.nz;
-    // planes per block: at least ~512 rows, and at least as many planes as the stencil reaches (P2 rows reach two: the
-    // blocks must couple to their neighbours only)
+    // planes per block: at least "direct_block_rows" rows (a solve is 3 dependent launches per block, each of them a few
+    // microseconds whatever the block's size: fewer, larger blocks while the dense inverses stay small), and at least as many
+    // planes as the stencil reaches (P2 rows reach two: the blocks must couple to their neighbours only)
     int64_t reach = 1;
     if (L.coded && L.ntable > 0) {
         std::vector<int> offs(256);
         HIP_TRY(hipMemcpy(offs.data(), L.offsets, 256 * sizeof(int), hipMemcpyDeviceToHost));
         for (int t = 0; t < L.ntable; ++t) reach = std::max<int64_t>(reach, (std::llabs((long long)offs[t]) + plane / 2) / plane);
     }
-    const int64_t G = std::max<int64_t>(reach, std::min<int64_t>(nz, (512 + plane - 1) / plane));
+    int64_t G = std::max<int64_t>(reach, std::min<int64_t>(nz, (c->direct_block_rows + plane - 1) / plane));
+    while (G > reach && G > 1 && G * plane > 2304) --G;               // (the dense blocks' size limit below)
     const int64_t p = G * plane;
     const int64_t nb = (nz + G - 1) / G;
     if (p > 2304 || nb * p * p * 8 > ((int64_t)3 << 29)) return 0;     // too large to store densely: PCG
@@ -3101,6 +3109,10 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "fuse_block_ez") {
         if (value != 0 && value != 11 && value != 19) return fail("fuse_block_ez must be 0, 11 or 19");
         c->fuse_block_ez = (int)value;
+    } else if (k == "direct_block_rows") {
+        if (value < 1 || value > 2304) return fail("direct_block_rows must be in 1..2304");
+        if (c->direct.tried) return fail("direct_block_rows must be chosen before the coarsest level is factored");
+        c->direct_block_rows = (int)value;
     } else if (k == "gen_odd_rows") {
         if (value < 0 || value > 10000) return fail("gen_odd_rows: rows in 10000");
         c->gen_odd_rows = (int)value;
@@ -3206,6 +3218,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         c->fuse_k_slab_min_sweeps = (int)value;
     } else if (k == "fuse_k_min_rows") {
         c->fuse_k_min_rows = value;
+    } else if (k == "fuse_k_small_rows") {
+        c->fuse_k_small_rows = value;
     } else if (k == "fuse_k5_min_rows") {
         c->fuse_k5_min_rows = value;
     } else if (k == "fuse_k4_min_rows") {
