@@ -513,7 +513,7 @@ def test_red_black_gauss_seidel_matches_oracle(dim, lo, hi, c, seed):
 @pytest.mark.parametrize("dim,N,seed", [(2, 16, None), (2, 32, 1), (2, 128, 2), (3, 8, 3), (3, 32, None)])
 def test_direct_coarsest_solve_is_exact(dim, N, seed):
     """The block-tridiagonal LU that stands in for spsolve (multigrid.py:239-241): one block (N=16),
-    several blocks of several planes (2-D) and one plane per block (3-D, 33^3 = BASELINE's coarsest grid);
+    several blocks of several planes (2-D) and one or two planes per block (3-D, 33^3 = BASELINE's coarsest grid);
     agrees with SuperLU and with the PCG fallback."""
     from scipy.sparse.linalg import spsolve
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
@@ -522,8 +522,11 @@ def test_direct_coarsest_solve_is_exact(dim, N, seed):
     rhs = rng.standard_normal((lvl.n, 1))
     exact = spsolve(lvl.A.tocsc(), rhs.ravel())
     sols = []
-    for direct in (1, 0):
-        with DeviceHierarchy(dim, 0, 0, c=N, coarse_direct=direct) as dev:
+    # (direct: the default blocks of at least 2048 rows -- two planes of the 33^3 grid, sixteen lines of the 129^2 one --, one
+    #  plane / line per block, round 2's blocks of 512 rows; 0: the PCG fallback)
+    for direct, block_rows in ((1, None), (1, 1), (1, 512), (0, None)):
+        kw = {} if block_rows is None else dict(direct_block_rows=block_rows)
+        with DeviceHierarchy(dim, 0, 0, c=N, coarse_direct=direct, **kw) as dev:
             dev.set_level(0, lvl.A, lvl.grid_index)
             dev.set_params(1, 1, 2 / 3, coarse_rtol=1e-15)
             dev.set_vector(0, "f", rhs)
@@ -533,7 +536,7 @@ def test_direct_coarsest_solve_is_exact(dim, N, seed):
             dev.set_vector(0, "f", lvl.b)                      # second solve re-uses the factorisation
             dev.coarse_solve()
             assert np.abs(dev.get_vector(0, "v") - lvl.exact()).max() <= 1e-11
-    assert rel_l2(sols[0], exact) <= 1e-12 and rel_l2(sols[1], exact) <= 1e-11
+    assert all(rel_l2(sol, exact) <= 1e-12 for sol in sols[:3]) and rel_l2(sols[3], exact) <= 1e-11
 
 
 @pytest.mark.parametrize("dim,lo,hi,c", [(2, 1, 3, 8), (3, 1, 3, 4)])
