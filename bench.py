@@ -450,7 +450,8 @@ def main():
         kernel_id = ("lat_gs2 x 5 launches (two colours each)" if pairs else "lat_march<MODE_GS> x 9 colours" if march else
                      "ell_cls_apply<2, MODE_GS> x 9 colours" if has_classes else "ell_apply_coded<0, 2, MODE_GS> x 9 colours")
     elif small:
-        kernel_id = "sdia_jacobi_small<%d>" % (3 if dim == 2 else 4)
+        need = (info["n_local"] + 1023) // 1024         # rows per thread: the smallest instance that covers the level
+        kernel_id = "sdia_jacobi_small<%d, %d>" % (3 if dim == 2 else 4, next(r for r in (1, 2, 3, 4, 5, 6, 8, 12, 16) if r >= need))
     elif march_k:
         shape = {0: "12, 2, 2", 1: "12, 4, 1", 2: "8, 3, 2", 3: "6, 4, 1", 4: "8, 3, 1", 5: "4, 6, 1", 6: "16, 3, 1", 7: "16, 2, 1"}[tuned.get("fuse_k_shape", 7)]
         kernel_id = f"sdia_jacobikc_finest<{march_k}, {shape}>"

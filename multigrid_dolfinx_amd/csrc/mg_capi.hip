@@ -1684,7 +1684,23 @@ int launch_jacobi_small(mg_context* c, const Level& L, int nw, const double* x_r
     for (int t = 0; t < 8; ++t) a.cm[t] = L.cm[t];
     a.n = (int)L.nloc; a.nw = nw; a.up1 = L.up[1]; a.up2 = L.up[2]; a.up3 = L.wu == 4 ? L.up[3] : 0; a.omega = c->omega;
     const size_t lds = js_lds_bytes(a.n, L.wu == 4 ? a.up3 : a.up2);
-    void (*kern)(JSArgs) = L.wu == 4 ? sdia_jacobi_small<4> : sdia_jacobi_small<3>;
+    // rows per thread: the smallest instance that covers the level
+    const int need = (a.n + 1023) / 1024;
+    void (*kern)(JSArgs) = nullptr;
+    auto pick = [&](auto wu_tag) {
+        constexpr int WU = decltype(wu_tag)::value;
+        if (need <= 1) kern = sdia_jacobi_small<WU, 1>;
+        else if (need <= 2) kern = sdia_jacobi_small<WU, 2>;
+        else if (need <= 3) kern = sdia_jacobi_small<WU, 3>;
+        else if (need <= 4) kern = sdia_jacobi_small<WU, 4>;
+        else if (need <= 5) kern = sdia_jacobi_small<WU, 5>;
+        else if (need <= 6) kern = sdia_jacobi_small<WU, 6>;
+        else if (need <= 8) kern = sdia_jacobi_small<WU, 8>;
+        else if (need <= 12) kern = sdia_jacobi_small<WU, 12>;
+        else kern = sdia_jacobi_small<WU, 16>;
+    };
+    if (L.wu == 4) pick(std::integral_constant<int, 4>{});
+    else pick(std::integral_constant<int, 3>{});
     MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), (size_t)150 * 1024));
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, a);
     HIP_TRY(hipGetLastError());

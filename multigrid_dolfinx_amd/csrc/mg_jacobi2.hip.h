@@ -1417,12 +1417,31 @@ __global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
 
 namespace mgk {
 
+// the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
+__device__ __forceinline__ double jk3_from_west(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13C, 0xF, 0xF, true);      // wave_ror:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13C, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double jk3_from_east(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xF, 0xF, true);      // wave_rol:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- all sweeps of a small level in one launch ------------------------------------------------------------------
 // The reference's shipped configuration (Multigrid_prototype.py:35-46) smooths levels of 4225 and 1089 unknowns fifty
-// times per leg: such a level (x twice, f, class bytes: 25 bytes per row) fits the LDS of one CU, so ONE 1024-thread
-// workgroup runs all nw sweeps with a barrier between them -- one launch instead of nw (or nw / 5).  Rows are handled
-// in linear row space with zero padding of the largest offset on both sides; arithmetic of sdia_cls_body<WU, ...>:
-// bit-identical to single sweeps.  Five- and seven-point levels with row classes.
+// times per leg: such a level fits one CU, so ONE 1024-thread workgroup runs all nw sweeps with a barrier between them
+// -- one launch instead of nw (or nw / 5).  Rows are handled in linear row space; thread t owns the rows t, t + 1024, ...
+// (RPT of them) and keeps their x, f and class in REGISTERS for the whole launch: a sweep reads only the +-nx (+-plane)
+// neighbours from the LDS image of the previous iterate (two copies, zero padding of the largest offset on both sides) --
+// the +-1 neighbours are the rows of the lanes next door (DPP; the first and last lane of a wave read the image) -- and
+// writes its new value into the other copy: three LDS accesses per row and sweep instead of eight (round 2 kept f, the
+// classes and x in LDS only), and whether a wave's rows all have the most frequent class is decided once, not per sweep:
+// 1.77 -> 1.37 us per sweep on 4225 rows, 0.68 -> 0.60 on 1089 (profiles/r03_small_kernel.txt; reading all of a thread's
+// neighbours ahead of the arithmetic, CH > 1 below, made it slower: 1.61).  What is left is instruction issue on ONE CU.
+// Arithmetic of sdia_cls_body<WU, ...> in the same order: bit-identical to single sweeps.  Five- and seven-point levels
+// with row classes.
 struct JSArgs {
     const double* x;        // row-based
     const double* f;
@@ -1436,17 +1455,15 @@ struct JSArgs {
     double omega;
 };
 
-inline size_t js_lds_bytes(int n, int pad) { return (size_t)256 * CLS_W * 8 + (size_t)2 * (n + 2 * pad) * 8 + (size_t)n * 8 + (size_t)n; }
+inline size_t js_lds_bytes(int n, int pad) { return (size_t)256 * CLS_W * 8 + (size_t)2 * (n + 2 * pad) * 8; }
 
-template <int WU>
+template <int WU, int RPT, bool DPP = true>
 __global__ __launch_bounds__(1024) void sdia_jacobi_small(JSArgs a) {
     extern __shared__ double j2_smem[];
     const int n = a.n, pad = WU == 4 ? a.up3 : a.up2, stride = n + 2 * pad;
     double* const sT = j2_smem;
     double* const sX = sT + 256 * CLS_W;                      // 2 x (pad | n | pad)
-    double* const sF = sX + 2 * stride;
-    unsigned char* const sC = reinterpret_cast<unsigned char*>(sF + n);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 2 * stride; i += 1024) sX[i] = 0.0;
     for (int i = tid; i < a.ncls * CLS_W; i += 1024) {
         double v = a.ctab[i];
@@ -1457,51 +1474,101 @@ __global__ __launch_bounds__(1024) void sdia_jacobi_small(JSArgs a) {
         sT[i] = v;
     }
     __syncthreads();
-    for (int r = tid; r < n; r += 1024) {
-        sX[pad + r] = a.x[r];
-        sF[r] = a.f[r];
-        sC[r] = a.cls[r];
+    double xr[RPT], fr[RPT];
+    int cr[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + 1024 * i;
+        const bool in = r < n;
+        xr[i] = in ? a.x[r] : 0.0;
+        fr[i] = in ? a.f[r] : 0.0;
+        cr[i] = in ? (int)a.cls[r] : 0;
+        if (in) sX[pad + r] = xr[i];
     }
     const double m0 = a.cm[0], m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5], m6 = a.cm[6];
     const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    // bit i: the i-th row of every lane of this wave has the most frequent class (entries in scalar registers) -- the classes
+    // do not change from sweep to sweep
+    unsigned fastmask = 0u;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(cr[i] != a.cmain) == 0ull))) fastmask |= 1u << i;
+    fastmask = (unsigned)__builtin_amdgcn_readfirstlane((int)fastmask);
     __syncthreads();
     for (int s = 0; s < a.nw; ++s) {
         const double* const src = sX + (s & 1) * stride + pad;
         double* const dst = sX + ((s + 1) & 1) * stride + pad;
-        for (int r0 = 0; r0 < n; r0 += 1024) {
-            const int r = r0 + tid;
-            const bool in = r < n;
-            const int rr = in ? r : n - 1;
-            const int c = sC[rr];
-            const double xc = src[rr];
-            double acc = 0.0, cf;
-            if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != a.cmain) == 0ull))) {
-                if (WU == 4) acc = fma(m0, src[rr - a.up3], acc);
-                acc = fma(m1, src[rr - a.up2], acc);
-                acc = fma(m2, src[rr - a.up1], acc);
-                acc = fma(m3, xc, acc);
-                acc = fma(m4, src[rr + a.up1], acc);
-                acc = fma(m5, src[rr + a.up2], acc);
-                if (WU == 4) acc = fma(m6, src[rr + a.up3], acc);
-                cf = mcf;
-            } else {
-                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
-                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
-                if (WU == 4) acc = fma(t01.x, src[rr - a.up3], acc);
-                acc = fma(t01.y, src[rr - a.up2], acc);
-                acc = fma(t23.x, src[rr - a.up1], acc);
-                acc = fma(t23.y, xc, acc);
-                acc = fma(t45.x, src[rr + a.up1], acc);
-                acc = fma(t45.y, src[rr + a.up2], acc);
-                if (WU == 4) acc = fma(t67.x, src[rr + a.up3], acc);
-                cf = t67.y;
+        // the neighbours of several of the thread's rows first, in straight-line code (read row by row inside the branches below,
+        // each row waited for its own reads: a sweep was a chain of RPT LDS latencies), CH rows at a time
+        constexpr int CH = 1;       // rows whose neighbours are read ahead of the arithmetic (more: slower, see above)
+#pragma unroll
+        for (int i0 = 0; i0 < RPT; i0 += CH) {
+            double xw[CH], xe[CH], xs[CH], xn[CH], xd[WU == 4 ? CH : 1], xu[WU == 4 ? CH : 1];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = i0 + j < RPT ? i0 + j : RPT - 1;
+                const int r = tid + 1024 * i;
+                const int rr = r < n ? r : n - 1;
+                if constexpr (DPP) {
+                    // (rows past the end hold zeros, like the image's padding; the wave's first / last lane: the row belongs to another wave)
+                    const double dw = jk3_from_west(xr[i]), de = jk3_from_east(xr[i]);
+                    xw[j] = lane == 0 ? src[rr - 1] : dw;
+                    xe[j] = lane == 63 ? src[rr + 1] : de;
+                } else {
+                    xw[j] = src[rr - 1];
+                    xe[j] = src[rr + 1];
+                }
+                xs[j] = src[rr - a.up2];
+                xn[j] = src[rr + a.up2];
+                if constexpr (WU == 4) {
+                    xd[j] = src[rr - a.up3];
+                    xu[j] = src[rr + a.up3];
+                }
             }
-            if (in) dst[r] = xc + cf * (sF[r] - acc);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (i0 + j >= RPT) continue;
+                const int i = i0 + j;
+                const int r = tid + 1024 * i;
+                const bool in = r < n;
+                const int c = cr[i];
+                const double xc = xr[i];
+                double acc = 0.0, cf;
+                if (fastmask >> i & 1u) {
+                    if (WU == 4) acc = fma(m0, xd[WU == 4 ? j : 0], acc);
+                    acc = fma(m1, xs[j], acc);
+                    acc = fma(m2, xw[j], acc);
+                    acc = fma(m3, xc, acc);
+                    acc = fma(m4, xe[j], acc);
+                    acc = fma(m5, xn[j], acc);
+                    if (WU == 4) acc = fma(m6, xu[WU == 4 ? j : 0], acc);
+                    cf = mcf;
+                } else {
+                    const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
+                    const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
+                    if (WU == 4) acc = fma(t01.x, xd[WU == 4 ? j : 0], acc);
+                    acc = fma(t01.y, xs[j], acc);
+                    acc = fma(t23.x, xw[j], acc);
+                    acc = fma(t23.y, xc, acc);
+                    acc = fma(t45.x, xe[j], acc);
+                    acc = fma(t45.y, xn[j], acc);
+                    if (WU == 4) acc = fma(t67.x, xu[WU == 4 ? j : 0], acc);
+                    cf = t67.y;
+                }
+                if (in) {
+                    const double o = xc + cf * (fr[i] - acc);
+                    dst[r] = o;
+                    xr[i] = o;
+                }
+            }
         }
         __syncthreads();
     }
-    const double* const res = sX + (a.nw & 1) * stride + pad;
-    for (int r = tid; r < n; r += 1024) a.out[r] = res[r];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + 1024 * i;
+        if (r < n) a.out[r] = xr[i];
+    }
 }
 
 }  // namespace mgk

@@ -89,17 +89,7 @@ template <int K, int NW, int LPW, int M, int TR, bool ESC = false> constexpr siz
     return sizeof(double) * (ESC ? (base + CLS_W - 1) / CLS_W * CLS_W + (size_t)(jk3_pool(K) + 1) * CLS_W : base);
 }
 
-// the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
-__device__ __forceinline__ double jk3_from_west(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13C, 0xF, 0xF, true);      // wave_ror:1
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13C, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double jk3_from_east(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xF, 0xF, true);      // wave_rol:1
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
+// (jk3_from_west / jk3_from_east -- the value of the lane next door through DPP -- live in mg_jacobi2.hip.h)
 
 template <int K, int NW, int LPW, int M, bool DPP, int PF, int TR, bool ESC = false>
 __device__ __forceinline__ void jk3_body(const JK3Args& a) {
