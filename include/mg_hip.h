@@ -202,13 +202,15 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "fuse_block"         1 = whole seven-point levels with row classes of "fuse_block_min_rows" <= rows < "fuse_block_max_rows" --
  *                          the middle levels, too small for the plane marches -- are relaxed K sweeps per launch on blocks of
  *                          32 x 32 x EZ cells that stay on the CU (mg_jacobiblk.hip.h), each block recomputing a halo of K
- *                          cells; bit-identical to single sweeps.  2 = whatever the level's size (tests), 0 = off.  Off by default: measured no
- *                          faster than one launch per sweep (0)
+ *                          cells; bit-identical to single sweeps.  2 = whatever the level's size (tests), 0 = off (1: alone the
+ *                          pass is no faster per sweep than one launch per sweep, but a cycle has a third of the launches --
+ *                          BASELINE config 3 132.8 -> 137.5 cycles/s)
  *     "fuse_block_min_rows"  see "fuse_block" (2^15)
  *     "fuse_block_max_rows"  see "fuse_block" (2^23)
  *     "fuse_block_k"       sweeps per launch of the block pass, 2..4; 0 = chosen by a cost model (rounds of workgroups x planes
- *                          loaded and relaxed per cell kept) (0)
- *     "fuse_block_ez"      planes per block of the block pass, 11 or 19; 0 = chosen likewise (0)
+ *                          loaded and relaxed per cell kept) (3)
+ *     "fuse_block_ez"      planes per block of the block pass, 11 or 19 (19 spills registers and is slower); 0 = chosen
+ *                          likewise (11)
  *     "direct_block_rows"  the coarsest level's exact solve (block-tridiagonal LU over groups of grid planes / lines) takes blocks
  *                          of at least this many rows, at most 2304: a solve is three dependent launches per block, so fewer,
  *                          larger blocks are faster while their dense inverses (rows^2 x 8 B each) stay small.  Before the first

@@ -260,11 +260,13 @@ struct mg_context {
     int fuse_restrict = 1;          // residual evaluated at the coarse nodes only when restricting by injection
     // K sweeps per launch on blocks resident on the CU (mg_jacobiblk.hip.h): whole 3-D levels with row classes of
     // fuse_block_min_rows <= rows < fuse_block_max_rows (below the plane marches' sizes); 2: whatever the size (tests).
-    // OFF: measured no faster than one launch per sweep (129^3: 13.2 us per sweep against 14.3; 65^3: 3.4 against 4.0;
-    // profiles/r03_block_pass.txt) -- the blocks' recomputed halos (x 2.2 cells) make the pass VALU-bound
-    int fuse_block = 0;
+    // Three sweeps per launch on blocks of 11 planes: alone no faster per sweep than one launch per sweep (129^3: 13.2 us
+    // against 14.3; 65^3: 3.9 against 4.0; profiles/r03_block_pass.txt), but a third of the launches inside a cycle, where a
+    // one-sweep launch costs 14.8 / 5.8 us: BASELINE config 3 132.8 -> 137.5 cycles/s (profiles/r03_block_cycles.txt).  Blocks
+    // of 19 planes spill and are slower (124.4).
+    int fuse_block = 1;
     int64_t fuse_block_min_rows = (int64_t)1 << 15, fuse_block_max_rows = (int64_t)1 << 23;
-    int fuse_block_k = 0, fuse_block_ez = 0;    // 0: chosen by the cost model; else 2..4 sweeps per launch / blocks of 11 or 19 planes
+    int fuse_block_k = 3, fuse_block_ez = 11;   // 0: chosen by the cost model; else 2..4 sweeps per launch / blocks of 11 or 19 planes
     int direct_block_rows = 2048;   // "direct_block_rows": rows per block of the coarsest level's block-tridiagonal LU, at least
     int gen_odd_rows = 0;           // "gen_odd_rows": mg_gen_poisson_level perturbs the diagonal of this many interior rows in 10000
     int cls_escape = 1;             // "row_escape": more than 255 distinct rows -> the frequent ones as classes, the rest read from their stored row

@@ -22,11 +22,13 @@
 // plane's first) -- and the host checks exactly that on the level's class table before it lets a level take this pass
 // (sdia_grid_decoupled).
 //
-// MEASURED (profiles/r03_block_pass.txt) and left OFF ("fuse_block" 0): 129^3 rows 13.2 us per sweep at best (three sweeps
-// per launch, blocks of 11 planes) against 14.3 for one launch per sweep, 65^3 3.4 against 4.0, 257^3 90 against 52 for the
-// K-sweep march.  The halos a block recomputes (2.2 cells relaxed per cell kept at K = 3) and the per-cell class test make
-// the pass VALU-bound, one 16-wave workgroup per CU cannot overlap its load phase with its sweeps, and blocks of 19 planes
-// spill (100-200 registers).  Kept as a tested alternative (bit-identical: test_two_sweep_kernel_is_bit_identical...).
+// MEASURED (profiles/r03_block_pass.txt, r03_block_cycles.txt): alone the pass is no faster per sweep than one launch per
+// sweep -- 129^3 rows 13.2 us per sweep at best (three sweeps per launch, blocks of 11 planes) against 14.3, 65^3 3.4 - 3.9
+// against 4.0, 257^3 90 against 52 for the K-sweep march: the halos a block recomputes (2.2 cells relaxed per cell kept at
+// K = 3) and the per-cell class test make it VALU-bound, one 16-wave workgroup per CU cannot overlap its load phase with its
+// sweeps, and blocks of 19 planes spill (100-200 registers).  Inside a cycle it still pays on the 129^3 and 65^3 levels,
+// where a one-sweep launch costs 14.8 / 5.8 us and the pass has a third of the launches: BASELINE config 3 132.8 -> 137.5
+// cycles/s with three sweeps per launch on blocks of 11 planes (the default; the cost model's choice of 19 planes: 124.4).
 #pragma once
 #include "mg_jacobik3d.hip.h"
 
