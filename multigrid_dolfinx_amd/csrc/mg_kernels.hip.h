@@ -1471,10 +1471,18 @@ __global__ void prolong_table(Grid gc, Grid gf, ProlongTable t, const double* __
     const int bi = 2 * (i >> 2), bj = gf.refine_y ? 2 * (j >> 2) : j, bk = 2 * (k >> 2);
     const int n = s_cnt[res];
     const double* const base = vc + gc.lead + (int64_t)(bk - gc.k0) * gc.plane + (int64_t)bj * gc.nx + bi;
+    // all (up to ten) coarse values first, then the sum in table order (a loop of n dependent iterations waits for every
+    // load by itself: n memory latencies per fine point)
+    double v[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) v[e] = e < n ? base[s_lin[res * 10 + e]] : 0.0;
     double s = 0.0;
-    for (int e = 0; e < n; ++e) {
-        const double term = s_w[res * 10 + e] * base[s_lin[res * 10 + e]];
-        s = e == 0 ? term : s + term;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        if (e < n) {
+            const double term = s_w[res * 10 + e] * v[e];
+            s = e == 0 ? term : s + term;
+        }
     }
     const int64_t o = gf.lead + (int64_t)kl * gf.plane + (int64_t)j * gf.nx + i;
     if (KEEP) err[o] = s;
@@ -1522,24 +1530,41 @@ __global__ void restrict_table(Grid gc, Grid gf, RestrictTable t, const double* 
         const int typ = (i & 1) | (gf.refine_y ? (j & 1) << 1 : 0) | (K & 1) << 2;
         const int n = lds ? s_cnt[typ] : t.count[typ];
         bool first = true;
-        for (int e = 0; e < n; ++e) {
-            int o0, o1, o2;
-            double w;
-            if (lds) {
-                const int pk = s_off[typ * RT_MAX + e];
-                o0 = (pk & 255) - 8; o1 = (pk >> 8 & 255) - 8; o2 = (pk >> 16 & 255) - 8;
-                w = s_w[typ * RT_MAX + e];
-            } else {
-                const int* o = t.off + ((size_t)typ * t.M + e) * 3;
-                o0 = o[0]; o1 = o[1]; o2 = o[2];
-                w = t.w[(size_t)typ * t.M + e];
+        // eight entries at a time: their fine values first (entries that fall on the boundary or past the table's end read
+        // nothing), then the sum in table order -- one entry per iteration waited for every load by itself
+        constexpr int NB = 8;
+        for (int e0 = 0; e0 < n; e0 += NB) {
+            double w[NB], v[NB];
+            bool use[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int e = e0 + u;
+                int o0 = 0, o1 = 0, o2 = 0;
+                w[u] = 0.0;
+                if (e < n) {
+                    if (lds) {
+                        const int pk = s_off[typ * RT_MAX + e];
+                        o0 = (pk & 255) - 8; o1 = (pk >> 8 & 255) - 8; o2 = (pk >> 16 & 255) - 8;
+                        w[u] = s_w[typ * RT_MAX + e];
+                    } else {
+                        const int* o = t.off + ((size_t)typ * t.M + e) * 3;
+                        o0 = o[0]; o1 = o[1]; o2 = o[2];
+                        w[u] = t.w[(size_t)typ * t.M + e];
+                    }
+                }
+                const int ii = fi + o0, jj = fj + o1, kk = fk + o2;
+                use[u] = e < n && !(ii <= 0 || ii >= gf.nx - 1 || kk <= 0 || kk >= gf.nz - 1) &&
+                         !(gf.refine_y && (jj <= 0 || jj >= gf.ny - 1));
+                v[u] = use[u] ? rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii] : 0.0;
             }
-            const int ii = fi + o0, jj = fj + o1, kk = fk + o2;
-            if (ii <= 0 || ii >= gf.nx - 1 || kk <= 0 || kk >= gf.nz - 1) continue;
-            if (gf.refine_y && (jj <= 0 || jj >= gf.ny - 1)) continue;
-            const double term = w * rf[gf.lead + (int64_t)(kk - gf.k0) * gf.plane + (int64_t)jj * gf.nx + ii];
-            s = first ? term : s + term;
-            first = false;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (use[u]) {
+                    const double term = w[u] * v[u];
+                    s = first ? term : s + term;
+                    first = false;
+                }
+            }
         }
     }
     fc[gc.lead + (int64_t)kl * gc.plane + (int64_t)j * gc.nx + i] = s;
