@@ -29,6 +29,9 @@
 // sweeps, and blocks of 19 planes spill (100-200 registers).  Inside a cycle it still pays on the 129^3 and 65^3 levels,
 // where a one-sweep launch costs 14.8 / 5.8 us and the pass has a third of the launches: BASELINE config 3 132.8 -> 137.5
 // cycles/s with three sweeps per launch on blocks of 11 planes (the default; the cost model's choice of 19 planes: 124.4).
+// Tried for the 19-plane blocks and dropped: f read again in every sweep instead of kept in registers, and the sweeps as a
+// run-time loop (a third of the code) -- still 60 to 160 spilled registers (the spills sit in the load phase: 19 x loads, 19
+// class bytes and their offsets in flight), 24.7 us per sweep on 129^3 rows, and the 11-plane shapes got slower too.
 #pragma once
 #include "mg_jacobik3d.hip.h"
 
