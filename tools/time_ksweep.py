@@ -17,12 +17,16 @@ with DeviceHierarchy.synthetic(3, 2, hi, c=8, mu1=50, mu2=50) as h:
     n = h.level_info(hi)["n_global"]
     ms = h.time_kernel("jacobi2!", hi, reps)
     print(f"{'two-sweep pass':44s} {ms:8.3f} ms = {ms / 2:6.3f} ms per sweep, {25 * n / ms / 1e6:7.1f} GB/s on 25 B/row", flush=True)
+    tuned = {}
     for spec in specs:
         for kv in spec.split(","):
             key, val = kv.split("=")
             if key not in ("form", "skip"):
                 h.set_tuning(key, int(val))
-        k = next(int(kv.split("=")[1]) for kv in spec.split(",") if kv.startswith("fuse_k="))
+                tuned[key] = int(val)
+        # sweeps per pass the library takes on a level of this size (mg_capi.hip: sweepsk_max)
+        k = min(tuned.get("fuse_k", 5), 3 if n < tuned.get("fuse_k4_min_rows", 0) else 5 if n < tuned.get("fuse_k_small_rows", 1 << 22)
+                else 4 if n < tuned.get("fuse_k5_min_rows", 1 << 26) else 5)
         form = next((kv.split("=")[1] for kv in spec.split(",") if kv.startswith("form=")), None)
         skip = next((kv.split("=")[1] for kv in spec.split(",") if kv.startswith("skip=")), None)
         name = "jacobik3" + (":skip" + skip if skip else "") + (":form" + form if form else "!")
