@@ -31,6 +31,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_c5_pmc_$N.d" -- python3 "$R/bench.py" --config c5 $SHORT > /dev/null 2> "$OUT/${TAG}_c5_pmc_$N.err"
   python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c5_pmc_$N.d" "$OUT/${TAG}_c5_pmc_$N.csv"
 done
+# the other configurations whose dominant launch has a traffic entry: C3 (four-sweep march on 257^3 rows), C2 (2-D K-sweep kernel)
+for CFG in c3 c2; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    N=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
+    echo "pmc $CFG $N"
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_${CFG}_pmc_$N.d" -- python3 "$R/bench.py" --config $CFG --steps 2 --warmup 1 --kernel-reps 4 --no-cpu-baseline > /dev/null 2> "$OUT/${TAG}_${CFG}_pmc_$N.err"
+    python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_${CFG}_pmc_$N.d" "$OUT/${TAG}_${CFG}_pmc_$N.csv"
+  done
+done
 echo "sq"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_c4_pmc_sq.d" -- python3 "$R/tools/pmc_ksweep.py" > "$OUT/${TAG}_c4_pmc_sq.log" 2>&1
 python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq.d" "$OUT/${TAG}_c4_pmc_sq.csv"
@@ -38,5 +47,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LD
 python3 "$R/profiles/summarize.py" pmc "$OUT/${TAG}_c4_pmc_sq2.d" "$OUT/${TAG}_c4_pmc_sq2.csv"
 cd "$R"
 echo "plain"; python3 bench.py > "$OUT/${TAG}_c4_bench_untraced.json" 2> "$OUT/${TAG}_c4_untraced.err"
-rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d "$OUT"/${TAG}_c5_pmc_*.d
+rm -rf "$OUT/${TAG}_c4_trace" "$OUT"/${TAG}_c4_pmc_*.d "$OUT"/${TAG}_c5_pmc_*.d "$OUT"/${TAG}_c3_pmc_*.d "$OUT"/${TAG}_c2_pmc_*.d
 echo "done"
