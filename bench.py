@@ -456,7 +456,11 @@ def main():
         shape = {0: "12, 2, 2", 1: "12, 4, 1", 2: "8, 3, 2", 3: "6, 4, 1", 4: "8, 3, 1", 5: "4, 6, 1", 6: "16, 3, 1", 7: "16, 2, 1"}[tuned.get("fuse_k_shape", 7)]
         kernel_id = f"sdia_jacobikc_finest<{march_k}, {shape}>"
     elif multi_k:
-        kernel_id = f"sdia_jacobik2d<{multi_k}, 40>"
+        # lines per region as mg_capi.hip chooses them: 16 while all tiles of the level run at once (two workgroups per CU), else 32
+        side = int(round(info["n_global"] ** 0.5))
+        tiles16 = -(-side // (128 - 2 * multi_k)) * -(-side // (16 - 2 * multi_k))
+        lines = tuned.get("fuse_2d_lines", 0) or (16 if tiles16 <= 2 * 256 else 32)
+        kernel_id = f"sdia_jacobik2d<{multi_k}, {lines}>"       # (the finest level of the 2-D configurations takes 64-line regions)
     elif pair_ms:
         # (without row classes: the round-2 structure of the pass on the stored rows, unless "fuse_plain" 1 asks for round 1's)
         plain = {0: "sdia_jacobi2p_finest<2, 12, 1>", 1: "sdia_jacobi2p_finest<2, 8, 2>", 2: "sdia_jacobi2p_finest<2, 16, 1>"}[

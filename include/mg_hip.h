@@ -211,6 +211,9 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          loaded and relaxed per cell kept) (3)
  *     "fuse_block_ez"      planes per block of the block pass, 11 or 19 (19 spills registers and is slower); 0 = chosen
  *                          likewise (11)
+ *     "fuse_2d_lines"      lines per region of the 2-D K-sweep kernel ("fuse_2d"): 64, 32 or 16; 0 = chosen per level -- 32 (two
+ *                          workgroups per CU: BASELINE config 2 451 -> 592 cycles/s against 64 lines), 16 on levels whose
+ *                          tiles then still all run at once (621) (0)
  *     "direct_block_rows"  the coarsest level's exact solve (block-tridiagonal LU over groups of grid planes / lines) takes blocks
  *                          of at least this many rows, at most 2304: a solve is three dependent launches per block, so fewer,
  *                          larger blocks are faster while their dense inverses (rows^2 x 8 B each) stay small.  Before the first

@@ -268,6 +268,7 @@ struct mg_context {
     int64_t fuse_block_min_rows = (int64_t)1 << 15, fuse_block_max_rows = (int64_t)1 << 23;
     int fuse_block_k = 3, fuse_block_ez = 11;   // 0: chosen by the cost model; else 2..4 sweeps per launch / blocks of 11 or 19 planes
     int direct_block_rows = 2048;   // "direct_block_rows": rows per block of the coarsest level's block-tridiagonal LU, at least
+    int fuse_2d_lines = 0;          // "fuse_2d_lines": lines per region of the 2-D K-sweep kernel (64, 32 or 16; 0: chosen per level)
     int gen_odd_rows = 0;           // "gen_odd_rows": mg_gen_poisson_level perturbs the diagonal of this many interior rows in 10000
     int cls_escape = 1;             // "row_escape": more than 255 distinct rows -> the frequent ones as classes, the rest read from their stored row
     int storage_auto = 1;           // "storage_auto": a level whose exact symmetry test / row dictionary fails is tried once more with 4 ulps
@@ -1522,19 +1523,35 @@ bool sweeps2d_ok(const mg_context* c, const Level& L) {
     return L.g.ny == 1 && L.up[1] == 1 && L.up[2] == L.g.nx && L.g.nx >= 8 && L.g.nz >= 8;
 }
 
-constexpr int kJKLines = 40;
-
-template <int K>
-int launch_jacobik_t(mg_context* c, const JKArgs& a) {
-    constexpr size_t lds = jk_lds_bytes<kJKLines>();
-    void (*const kern)(JKArgs) = sdia_jacobik2d<K, kJKLines>;
+// Lines per region ("fuse_2d_lines"; 0 = chosen here).  Regions of 32 lines (four cells per thread, 56 registers, 80 KB of LDS)
+// run two workgroups per CU, which hides the barriers of one behind the other: 0.039 ms per five sweeps on 2049^2 rows against
+// 0.049 with 64 lines although a sweep keeps 22 of 32 lines instead of 54 of 64 -- BASELINE config 2 451 -> 592 cycles/s
+// (profiles/r03_2d_lines.txt).  A launch on a small level takes as long as ONE workgroup does, about 2 us plus 1.3 us per cell
+// a thread owns: 16 lines (two cells) while all tiles still run at once.
+template <int K, int H>
+int launch_jacobik_th(mg_context* c, const JKArgs& a) {
+    constexpr size_t lds = jk_lds_bytes<H>();
+    void (*const kern)(JKArgs) = sdia_jacobik2d<K, H>;
     MG_TRY(allow_large_lds(c, reinterpret_cast<const void*>(kern), lds));
     JKArgs b = a;
     b.ntx = (a.nx + JK_W - 2 * K - 1) / (JK_W - 2 * K);
-    b.nty = (a.nlines + kJKLines - 2 * K - 1) / (kJKLines - 2 * K);
+    b.nty = (a.nlines + H - 2 * K - 1) / (H - 2 * K);
     hipLaunchKernelGGL(kern, dim3((unsigned)(b.ntx * b.nty)), dim3(1024), lds, c->stream, b);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int K>
+int launch_jacobik_t(mg_context* c, const JKArgs& a) {
+    const int64_t cus = std::max(1, c->prop.multiProcessorCount);
+    const int64_t ntx = (a.nx + JK_W - 2 * K - 1) / (JK_W - 2 * K);
+    int best = c->fuse_2d_lines;
+    if (!best) best = K <= 5 && ntx * ((a.nlines + 16 - 2 * K - 1) / (16 - 2 * K)) <= 2 * cus ? 16 : 32;
+    switch (best) {
+        case 16: return launch_jacobik_th<K, 16>(c, a);
+        case 32: return launch_jacobik_th<K, 32>(c, a);
+        default: return launch_jacobik_th<K, 64>(c, a);
+    }
 }
 
 // out = K Jacobi sweeps applied to x (2 <= K <= 5)
@@ -3131,6 +3148,9 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
         if (value < 1 || value > 2304) return fail("direct_block_rows must be in 1..2304");
         if (c->direct.tried) return fail("direct_block_rows must be chosen before the coarsest level is factored");
         c->direct_block_rows = (int)value;
+    } else if (k == "fuse_2d_lines") {
+        if (value != 0 && value != 16 && value != 32 && value != 64) return fail("fuse_2d_lines must be 0, 16, 32 or 64");
+        c->fuse_2d_lines = (int)value;
     } else if (k == "gen_odd_rows") {
         if (value < 0 || value > 10000) return fail("gen_odd_rows: rows in 10000");
         c->gen_odd_rows = (int)value;

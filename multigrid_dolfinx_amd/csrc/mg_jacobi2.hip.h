@@ -1301,6 +1301,18 @@ __global__ __launch_bounds__(NW * WAVE) void sdia_jacobi2_finest(J2Args a) {
 
 namespace mgk {
 
+// the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
+__device__ __forceinline__ double jk3_from_west(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13C, 0xF, 0xF, true);      // wave_ror:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13C, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double jk3_from_east(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xF, 0xF, true);      // wave_rol:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- K sweeps in one launch on 2-D levels (five-point rows through row classes) --------------------------------
 // The reference's own configurations are 2-D (Multigrid_prototype.py:35-46: 64 x 64, V(50,50)); a 2-D level is a few
 // MB at most, so its sweeps are launch- and latency-bound, not bandwidth-bound.  Here a 1024-thread workgroup loads
@@ -1325,31 +1337,40 @@ struct JKArgs {
 
 constexpr int JK_W = 128;
 
-template <int H> constexpr size_t jk_lds_bytes() { return (size_t)H * JK_W * (3 * sizeof(double) + 1) + 256 * CLS_W * sizeof(double); }
+template <int H> constexpr size_t jk_lds_bytes() { return (size_t)2 * H * JK_W * sizeof(double) + 256 * CLS_W * sizeof(double); }
 
+// (round 3: a thread keeps x, f and the class of its H / 8 cells -- the same column of the region, eight lines apart -- in
+//  registers; LDS holds the two copies of the iterate only, the +-1 neighbours come from the lanes next door (DPP; a wave is 64
+//  consecutive cells of a line, its first and last lane read the LDS copy) and a cell costs three LDS accesses per sweep
+//  instead of eight.  H = 32 or 16: two workgroups per CU, one computing while the other waits at its barrier -- faster than one
+//  workgroup on 64 lines although a sweep keeps fewer of the lines, see launch_jacobik_t.)
 template <int K, int H>
 __global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
-    constexpr int W = JK_W, NT = 1024, CELLS = W * H;
+    constexpr int W = JK_W, NT = 1024, CELLS = W * H, PER = CELLS / NT;
     static_assert(CELLS % NT == 0, "whole rounds of the workgroup");
     extern __shared__ double j2_smem[];
     double* const sT = j2_smem;                               // 256 x 8 (classes in use), [7] = omega / diagonal
     double* const sX = sT + 256 * CLS_W;                      // 2 x CELLS
-    double* const sF = sX + 2 * CELLS;                        // CELLS
-    unsigned char* const sC = reinterpret_cast<unsigned char*>(sF + CELLS);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int tix = (int)(blockIdx.x % (unsigned)a.ntx), tiy = (int)(blockIdx.x / (unsigned)a.ntx);
     const int tx0 = tix * (W - 2 * K) - K, ty0 = tiy * (H - 2 * K) - K;       // grid position of cell (0, 0)
     const int64_t r00 = (int64_t)ty0 * a.nx + tx0;
+    const int ex = tid % W, ey0 = tid / W;                   // the thread's cells: (ex, ey0 + (NT / W) i)
 
-    // ---- region -> LDS (rows outside the level: zeros, class 0) ----
+    // ---- region -> registers and the first LDS copy (rows outside the level: zeros, class 0) ----
+    double xr[PER], fr[PER];
+    int cr[PER];
+    unsigned okmask = 0u;
 #pragma unroll
-    for (int i = 0; i < CELLS / NT; ++i) {
+    for (int i = 0; i < PER; ++i) {
         const int idx = tid + i * NT;
         const int64_t row = r00 + (int64_t)(idx / W) * a.nx + (idx % W);
         const bool ok = row >= 0 && row < a.n;
-        sX[idx] = ok ? a.x[row] : 0.0;
-        sF[idx] = ok ? a.f[row] : 0.0;
-        sC[idx] = ok ? a.cls[row] : (unsigned char)0;
+        xr[i] = ok ? a.x[row] : 0.0;
+        fr[i] = ok ? a.f[row] : 0.0;
+        cr[i] = ok ? (int)a.cls[row] : 0;
+        okmask |= (ok ? 1u : 0u) << i;
+        sX[idx] = xr[i];
     }
     for (int i = tid; i < a.ncls * CLS_W; i += NT) {
         double v = a.ctab[i];
@@ -1361,31 +1382,40 @@ __global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
     }
     const double m1 = a.cm[1], m2 = a.cm[2], m3 = a.cm[3], m4 = a.cm[4], m5 = a.cm[5];
     const double mcf = a.omega * (1.0 / (m3 != 0.0 ? m3 : 1.0));
+    // bit i: the i-th cell of every lane of this wave has the most frequent class (the classes do not change between sweeps)
+    unsigned fastmask = 0u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(cr[i] != a.cmain) == 0ull))) fastmask |= 1u << i;
+    fastmask = (unsigned)__builtin_amdgcn_readfirstlane((int)fastmask);
     __syncthreads();
 
-    // ---- K sweeps in LDS: sweep s is exact on [s, W-s) x [s, H-s) ----
+    // ---- K sweeps: sweep s is exact on [s, W-s) x [s, H-s) ----
 #pragma unroll
     for (int s = 1; s <= K; ++s) {
         const double* const src = sX + ((s - 1) & 1) * CELLS;
         double* const dst = sX + (s & 1) * CELLS;
 #pragma unroll
-        for (int i = 0; i < CELLS / NT; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int idx = tid + i * NT;
-            const int ex = idx % W, ey = idx / W;                       // a wave: 64 consecutive cells of one line
+            const int ey = ey0 + (NT / W) * i;                          // a wave: 64 consecutive cells of one line
             if (ey < s || ey >= H - s) continue;                        // (uniform within the wave)
-            const int c = sC[idx];
-            const double xs = src[idx - W], xw = src[idx - 1], xc = src[idx], xe = src[idx + 1], xn = src[idx + W];
+            const double xc = xr[i];
+            const double dw = jk3_from_west(xc), de = jk3_from_east(xc);
+            const double xw = lane == 0 ? src[idx - 1] : dw;            // (the neighbour belongs to another wave)
+            const double xe = lane == 63 ? src[idx + 1] : de;
+            const double xs = src[idx - W], xn = src[idx + W];
             double o;
-            if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != a.cmain) == 0ull))) {
+            if (fastmask >> i & 1u) {
                 double acc = 0.0;
                 acc = fma(m1, xs, acc);
                 acc = fma(m2, xw, acc);
                 acc = fma(m3, xc, acc);
                 acc = fma(m4, xe, acc);
                 acc = fma(m5, xn, acc);
-                o = xc + mcf * (sF[idx] - acc);
+                o = xc + mcf * (fr[i] - acc);
             } else {
-                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
+                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cr[i]);
                 const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
                 double acc = 0.0;
                 acc = fma(t01.y, xs, acc);
@@ -1393,41 +1423,30 @@ __global__ __launch_bounds__(1024) void sdia_jacobik2d(JKArgs a) {
                 acc = fma(t23.y, xc, acc);
                 acc = fma(t45.x, xe, acc);
                 acc = fma(t45.y, xn, acc);
-                o = xc + t67.y * (sF[idx] - acc);
+                o = xc + t67.y * (fr[i] - acc);
             }
-            const int64_t row = r00 + (int64_t)ey * a.nx + ex;
-            if (ex >= s && ex < W - s) dst[idx] = (row >= 0 && row < a.n) ? o : 0.0;
+            if (ex >= s && ex < W - s) {
+                o = (okmask >> i & 1u) ? o : 0.0;
+                dst[idx] = o;
+                xr[i] = o;
+            }
         }
         __syncthreads();
     }
 
     // ---- the inner cells that lie on the grid ----
-    const double* const res = sX + (K & 1) * CELLS;
 #pragma unroll
-    for (int i = 0; i < CELLS / NT; ++i) {
-        const int idx = tid + i * NT;
-        const int ex = idx % W, ey = idx / W;
+    for (int i = 0; i < PER; ++i) {
+        const int ey = ey0 + (NT / W) * i;
         const int gx = tx0 + ex, gy = ty0 + ey;
         if (ex >= K && ex < W - K && ey >= K && ey < H - K && gx < a.nx && gy < a.nlines)
-            a.out[(int64_t)gy * a.nx + gx] = res[idx];
+            a.out[(int64_t)gy * a.nx + gx] = xr[i];
     }
 }
 
 }  // namespace mgk
 
 namespace mgk {
-
-// the value of lane - 1 (lane 0: lane 63) / lane + 1 (lane 63: lane 0) of the wave
-__device__ __forceinline__ double jk3_from_west(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13C, 0xF, 0xF, true);      // wave_ror:1
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13C, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double jk3_from_east(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xF, 0xF, true);      // wave_rol:1
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
 
 // ---- all sweeps of a small level in one launch ------------------------------------------------------------------
 // The reference's shipped configuration (Multigrid_prototype.py:35-46) smooths levels of 4225 and 1089 unknowns fifty

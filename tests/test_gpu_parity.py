@@ -1394,14 +1394,17 @@ def test_escape_rows_keep_the_class_path(case):
 
 @pytest.mark.parametrize("c,lo,hi", [(8, 1, 4), (5, 1, 5), (3, 2, 6)])
 def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi):
-    """mg_jacobi2.hip.h, sdia_jacobik2d: up to five Jacobi sweeps per launch on 2-D levels (tile region in LDS, the
-    exact region shrinks by one ring per sweep) must reproduce single sweeps bit for bit -- for sweep counts that
+    """mg_jacobi2.hip.h, sdia_jacobik2d: up to five Jacobi sweeps per launch on 2-D levels (a region of the grid in LDS and
+    registers, the exact part shrinks by one ring per sweep) must reproduce single sweeps bit for bit -- for sweep counts that
     split into different launch sizes, grids that are not a multiple of the tile, and whole V-cycles."""
     from multigrid_dolfinx_amd.hierarchy import DeviceHierarchy
     rng = np.random.default_rng(c)
     want = {}
+    # (fuse_2d_lines: regions of 64 / 32 / 16 lines -- eight, four, two cells per thread; 0, the default: chosen per level)
     for kw in (dict(fuse_2d=0, fuse_small=0), dict(), dict(fuse_small=0), dict(fuse_small=0, fuse_2d_k=2), dict(fuse_2d_k=3),
-               dict(fuse_small=0, fuse_2d_k=4), dict(rows_per_lane=1)):
+               dict(fuse_small=0, fuse_2d_k=4), dict(rows_per_lane=1), dict(fuse_small=0, fuse_2d_lines=64),
+               dict(fuse_small=0, fuse_2d_lines=32, fuse_2d_k=4), dict(fuse_small=0, fuse_2d_lines=16),
+               dict(fuse_small=0, fuse_2d_lines=16, fuse_2d_k=3)):
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
         with DeviceHierarchy.synthetic(2, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
