@@ -298,6 +298,8 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *     "march_shape"        ... 0 = 12 waves x 2 grid lines per workgroup, 1 = 16 x 2 (0)
  *     "fuse_small"         all Jacobi sweeps of a smoother call in ONE launch on levels with row classes that fit one CU's
  *                          LDS (a few thousand rows: the reference's own 65^2 / 33^2 levels) (1); bit-identical
+ *     "fuse_small_2d_rows" ... on 2-D levels only up to this many rows: larger ones (65^2) are faster through the K-sweep 2-D
+ *                          kernel, ten launches of a dozen small workgroups instead of one launch of one workgroup (2048)
  *     "fuse_2d"            up to "fuse_2d_k" Jacobi sweeps per launch on 2-D five-point levels with row classes (1);
  *                          bit-identical to single sweeps
  *     "fuse_2d_k"          ... at most this many per launch, 2..5 (5)

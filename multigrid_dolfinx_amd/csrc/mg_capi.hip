@@ -310,6 +310,7 @@ struct mg_context {
     int march_sweeps = 1;           // one-sweep class kernels as a plane march on large 3-D levels (sdia_sweep1c)
     int64_t march_min_rows = (int64_t)1 << 22;
     int march_shape = 0;            // 0 = 12 waves x 2 lines, 1 = 16 waves x 2 lines
+    int64_t fuse_small_2d_rows = 2048;  // ... 2-D levels only up to this many rows (larger ones: the K-sweep 2-D kernel)
     int fuse_small = 1;             // all sweeps of a level that fits one CU's LDS in one launch (sdia_jacobi_small)
     int fuse_2d = 1;                // K sweeps per launch on 2-D levels with row classes (sdia_jacobik2d)
     int fuse_2d_k = 5;              // ... at most this many (2..5)
@@ -1693,6 +1694,9 @@ bool small_level_ok(const mg_context* c, const Level& L) {
     if (L.wu != 3 && L.wu != 4) return false;
     if (L.up[1] != 1 || L.up[2] <= 1 || (L.wu == 4 && L.up[3] <= L.up[2])) return false;
     const int pad = L.wu == 4 ? L.up[3] : L.up[2];
+    // (2-D levels of more than "fuse_small_2d_rows" rows are faster through the K-sweep 2-D kernel -- ten launches of a dozen
+    //  small workgroups on as many CUs instead of one launch of one workgroup: 65^2 rows 55 against 72 us per 50 sweeps)
+    if (L.wu == 3 && L.nloc > c->fuse_small_2d_rows && sweeps2d_ok(c, L)) return false;
     return L.nloc <= 16384 && js_lds_bytes((int)L.nloc, pad) <= (size_t)150 * 1024;
 }
 
@@ -3206,6 +3210,8 @@ int mg_set_tuning(mg_handle c, const char* key, int64_t value) {
     } else if (k == "march_shape") {
         if (value < 0 || value > 1) return fail("march_shape must be 0 or 1");
         c->march_shape = (int)value;
+    } else if (k == "fuse_small_2d_rows") {
+        c->fuse_small_2d_rows = value;
     } else if (k == "fuse_small") {
         c->fuse_small = value != 0;
     } else if (k == "fuse_2d") {
