@@ -1404,7 +1404,9 @@ def test_k_sweep_kernel_on_2d_levels_is_bit_identical_to_single_sweeps(c, lo, hi
     for kw in (dict(fuse_2d=0, fuse_small=0), dict(), dict(fuse_small=0), dict(fuse_small=0, fuse_2d_k=2), dict(fuse_2d_k=3),
                dict(fuse_small=0, fuse_2d_k=4), dict(rows_per_lane=1), dict(fuse_small=0, fuse_2d_lines=64),
                dict(fuse_small=0, fuse_2d_lines=32, fuse_2d_k=4), dict(fuse_small=0, fuse_2d_lines=16),
-               dict(fuse_small=0, fuse_2d_lines=16, fuse_2d_k=3)):
+               dict(fuse_small=0, fuse_2d_lines=16, fuse_2d_k=3),
+               # (the one-launch smoother also on the levels the 2-D kernel takes by default: more than 2048 rows)
+               dict(fuse_small_2d_rows=16384)):
         tune = {k: v for k, v in kw.items() if k.startswith("fuse_")}
         make = {k: v for k, v in kw.items() if not k.startswith("fuse_")}
         with DeviceHierarchy.synthetic(2, lo, hi, c=c, mu1=2, mu2=2, **make) as dev:
