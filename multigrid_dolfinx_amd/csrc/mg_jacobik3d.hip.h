@@ -305,21 +305,23 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
 
     // ---- the three forms of a step (chosen per wave and step; all of them read and write the images alike) ----
     // Straight-line form.  COL = false: every cell has the interior stencil, entries in scalar registers.  COL = true:
-    // a cell's class depends on its lane only (tile columns along the x boundary, away from the other boundaries): the
-    // entries of the lane's row come from the class table once per cell group and phase.
+    // a cell's class is the same in all planes of the ring -- it depends on the lane (tile columns along the x boundary) and / or
+    // on the cell's grid line (tile rows along the y boundary), away from the first and last planes: the entries of each cell's
+    // row come from the class table once per cell and phase.  (Until the y boundary took this form too its tiles ran the
+    // general one, 1.6 x slower -- and on a level with one round of workgroups, 257^3, the slowest tiles ARE the launch.)
     auto phase_a_fast = [&](auto col_tag, const double (&X)[NC]) __attribute__((always_inline)) {
         constexpr bool COL = decltype(col_tag)::value;
 #pragma unroll
         for (int r = 0; r < M; ++r) {
-            double k0 = m0, k6 = m6, kcf = mcf;
-            if constexpr (COL) {
-                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, r));
-                const dvec2_t t01 = tr[0], t67 = tr[3];
-                k0 = t01.x; k6 = t67.x; kcf = t67.y;
-            }
 #pragma unroll
             for (int l = 0; l < LPW; ++l) {
                 const int c = l * M + r, iw = lwof(c);
+                double k0 = m0, k6 = m6, kcf = mcf;
+                if constexpr (COL) {
+                    const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, c));
+                    const dvec2_t t01 = tr[0], t67 = tr[3];
+                    k0 = t01.x; k6 = t67.x; kcf = t67.y;
+                }
                 double nw = X[c];
 #pragma unroll
                 for (int t = 1; t <= K; ++t) {
@@ -339,16 +341,6 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
     //  inside the branches of the three forms makes the compiler spill hundreds of registers)
     auto phase_b_fast = [&](auto col_tag, const int t) __attribute__((always_inline)) {
         constexpr bool COL = decltype(col_tag)::value;
-        double k1[M], k2[M], k3[M], k4[M], k5[M];
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            k1[r] = m1; k2[r] = m2; k3[r] = m3; k4[r] = m4; k5[r] = m5;
-            if constexpr (COL) {
-                const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, r));
-                const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
-                k1[r] = t01.y; k2[r] = t23.x; k3[r] = t23.y; k4[r] = t45.x; k5[r] = t45.y;
-            }
-        }
         const double* const img = image(t - 1);
         double v[LPW][M], ys[M], yn[M];
 #pragma unroll
@@ -380,12 +372,18 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
 #pragma unroll
             for (int r = 0; r < M; ++r) {
                 const int c = l * M + r;
+                double k1 = m1, k2 = m2, k3 = m3, k4 = m4, k5 = m5;
+                if constexpr (COL) {
+                    const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * cls_of(0, c));
+                    const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2];
+                    k1 = t01.y; k2 = t23.x; k3 = t23.y; k4 = t45.x; k5 = t45.y;
+                }
                 double s = acc[t - 1][c];
-                s = fma(k1[r], l > 0 ? v[l > 0 ? l - 1 : 0][r] : ys[r], s);
-                s = fma(k2[r], yw[r], s);
-                s = fma(k3[r], v[l][r], s);
-                s = fma(k4[r], ye[r], s);
-                s = fma(k5[r], l + 1 < LPW ? v[l + 1 < LPW ? l + 1 : l][r] : yn[r], s);
+                s = fma(k1, l > 0 ? v[l > 0 ? l - 1 : 0][r] : ys[r], s);
+                s = fma(k2, yw[r], s);
+                s = fma(k3, v[l][r], s);
+                s = fma(k4, ye[r], s);
+                s = fma(k5, l + 1 < LPW ? v[l + 1 < LPW ? l + 1 : l][r] : yn[r], s);
                 acc[t - 1][c] = s;
             }
         }
@@ -515,8 +513,8 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
             }
             fast |= (unsigned long long)m << (K * NC);
         }
-        // which form: 0 = interior stencil everywhere in this wave's cells of the planes k .. k+K, 1 = classes that depend on
-        // the lane only -- both only where every row the step touches exists (planes k-1 .. k+K+1 through sh) or lies on a
+        // which form: 0 = interior stencil everywhere in this wave's cells of the planes k .. k+K, 1 = every cell's class the
+        // same in all those planes -- both only where every row the step touches exists (planes k-1 .. k+K+1 through sh) or lies on a
         // neighbouring slab (there a level's values beyond its plane range are wrong instead of zero, and reach no
         // result) --, 2 = general
         int form = 2;
@@ -528,7 +526,7 @@ __device__ __forceinline__ void jk3_body(const JK3Args& a) {
 #pragma unroll
                 for (int j = 0; j <= K; ++j)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) same = same && cls_of(j, c) == cls_of(0, c % M);
+                    for (int c = 0; c < NC; ++c) same = same && cls_of(j, c) == cls_of(0, c);
                 if (__builtin_amdgcn_readfirstlane((int)(__ballot(!same) == 0ull))) form = 1;
             }
         }
