@@ -207,10 +207,9 @@ int mg_set_restriction_table(mg_handle h, int max_entries, const int* count /*[8
  *                          BASELINE config 3 132.8 -> 137.5 cycles/s)
  *     "fuse_block_min_rows"  see "fuse_block" (2^15)
  *     "fuse_block_max_rows"  see "fuse_block" (2^23)
- *     "fuse_block_k"       sweeps per launch of the block pass, 2..4; 0 = chosen by a cost model (rounds of workgroups x planes
- *                          loaded and relaxed per cell kept) (3)
- *     "fuse_block_ez"      planes per block of the block pass, 11 or 19 (19 spills registers and is slower); 0 = chosen
- *                          likewise (11)
+ *     "fuse_block_k"       sweeps per launch of the block pass, 2..4; 0 = three, four on levels whose blocks then all run at
+ *                          once (65^3 rows) (0)
+ *     "fuse_block_ez"      planes per block of the block pass, 11 or 19 (19 spills registers and is slower) (11)
  *     "fuse_2d_lines"      lines per region of the 2-D K-sweep kernel ("fuse_2d"): 64, 32 or 16; 0 = chosen per level -- 32 (two
  *                          workgroups per CU: BASELINE config 2 451 -> 592 cycles/s against 64 lines), 16 on levels whose
  *                          tiles then still all run at once (621) (0)

@@ -109,6 +109,15 @@ __global__ __launch_bounds__(1024) void sdia_jacobi_block(JBArgs a) {
             r += pstep;
         }
     }
+    // bit z: cell z of every lane of this wave has the most frequent class (entries in scalar registers) -- decided once, the
+    // classes do not change from sweep to sweep
+    unsigned fastz = 0u;
+#pragma unroll
+    for (int z = 0; z < EZ; ++z) {
+        const int c = (int)((cl[z >> 2] >> (8 * (z & 3))) & 255u);
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != cmain) == 0ull))) fastz |= 1u << z;
+    }
+    fastz = (unsigned)__builtin_amdgcn_readfirstlane((int)fastz);
     // LDS addresses as `register + 16-bit immediate`: one register per eight planes (64 KB) for the thread's own cell and for
     // the cells of the lines below / above (element offsets, pinned: left alone the compiler keeps one per plane)
     constexpr int NG = (EZ + 7) / 8;
@@ -135,9 +144,8 @@ __global__ __launch_bounds__(1024) void sdia_jacobi_block(JBArgs a) {
             const double xc = xr[z], up = xr[z + 1];
             const double xw = jk3_from_west(xc), xe = jk3_from_east(xc);
             const double xs = sX[bs[z >> 3] + (z & 7) * E * E], xn = sX[bn[z >> 3] + (z & 7) * E * E];
-            const int c = (int)((cl[z >> 2] >> (8 * (z & 3))) & 255u);
             double acc, cf;
-            if (__builtin_amdgcn_readfirstlane((int)(__ballot(c != cmain) == 0ull))) {
+            if (fastz >> z & 1u) {
                 acc = fma(m0, below, 0.0);
                 acc = fma(m1, xs, acc);
                 acc = fma(m2, xw, acc);
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(1024) void sdia_jacobi_block(JBArgs a) {
                 acc = fma(m6, up, acc);
                 cf = mcf;
             } else {
+                const int c = (int)((cl[z >> 2] >> (8 * (z & 3))) & 255u);
                 const dvec2_t* const tr = reinterpret_cast<const dvec2_t*>(sT + CLS_W * c);
                 const dvec2_t t01 = tr[0], t23 = tr[1], t45 = tr[2], t67 = tr[3];
                 acc = fma(t01.x, below, 0.0);
