@@ -1726,6 +1726,13 @@ int launch_jacobi_small(mg_context* c, const Level& L, int nw, const double* x_r
     return 0;
 }
 
+// a slab level on which calls of enough sweeps take the K-sweep march with K-plane exchanges (the same answer on every rank)
+bool slab_ksweep_level(const mg_context* c, const Level& L) {
+    return !L.replicated && c->comm.active() && c->fuse_k >= 3 && c->fuse_sweeps && c->fuse_classes && c->use_classes && c->use_sdia &&
+           L.hd >= 2 && c->halo_planes == 1 && !L.flat && L.g.nx >= 32 && L.g.ny >= 32 &&
+           min_slab_rows(L) >= std::max<int64_t>(8 * L.g.plane, c->fuse_k_slab_min_rows);
+}
+
 // nw Jacobi sweeps; v halos must be valid on entry and are valid on exit.
 int smooth(mg_context* c, int level, int nw) {
     Level& L = c->L[level];
@@ -1819,9 +1826,7 @@ int smooth(mg_context* c, int level, int nw) {
     // slab itself, so there is no boundary chain: two launches and one grouped send / receive per K sweeps.  With the
     // overlap on, the planes the neighbours wait for are relaxed first (one launch), and travel on the communication
     // stream while a second launch relaxes the rest.  (Everything that decides is the same on every rank.)
-    if (dist && nw >= c->fuse_k_slab_min_sweeps && c->fuse_k >= 3 && c->fuse_sweeps && c->fuse_classes && c->use_classes && c->use_sdia && L.hd >= 2 &&
-        c->halo_planes == 1 && !L.flat && L.g.nx >= 32 && L.g.ny >= 32 &&
-        min_slab_rows(L) >= std::max<int64_t>(8 * L.g.plane, c->fuse_k_slab_min_rows)) {
+    if (dist && nw >= c->fuse_k_slab_min_sweeps && slab_ksweep_level(c, L)) {
         if (L.cls_halo == 0) MG_TRY(ensure_class_halos(c, L));
         if (L.cls_halo == 1) {
             const int kmax = std::min(std::min(c->fuse_k, 5), L.hd);
@@ -2362,7 +2367,12 @@ int prepare_cycle(mg_context* c, int level) {
             if (c->L[l].mc_ok < 0 && !c->L[l].flat) MG_TRY(check_coloring(c, c->L[l]));
     if (c->comm.active())
         for (int l = 1; l <= level; ++l)
-            if (!c->L[l].replicated) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].sw));
+            if (!c->L[l].replicated) {
+                MG_TRY(vec_alloc(c, c->L[l], &c->L[l].sw));
+                // (the neighbours' class bytes next to the slab: allocations, exchanges and a vote -- not inside a capture)
+                if (c->L[l].cls_halo == 0 && slab_ksweep_level(c, c->L[l]) && std::max(c->mu1, c->mu2) >= c->fuse_k_slab_min_sweeps)
+                    MG_TRY(ensure_class_halos(c, c->L[l]));
+            }
     if (c->keep_err)
         for (int l = 1; l <= level; ++l) MG_TRY(vec_alloc(c, c->L[l], &c->L[l].err));
     return 0;
