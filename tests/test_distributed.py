@@ -102,9 +102,7 @@ def test_asynchronous_rccl_code_path_with_in_process_stand_in(world, dim, lo, hi
 @pytest.mark.parametrize("world,dim,lo,hi,c,rep,overlap,tune", [
     (2, 3, 1, 3, 4, 0, 1, "graph_comm=0"), (2, 3, 1, 3, 4, 0, 1, "graph_comm=1"), (4, 3, 1, 3, 4, 0, 0, "graph_comm=1"),
     (3, 2, 1, 3, 8, 1000, 1, "graph_comm=1"), (2, 3, 2, 4, 8, 300000, 1, "graph_comm=1,fuse_min_rows=0"),
-    (4, 3, 2, 4, 8, 300000, 1, "graph_comm=1,fuse_min_rows=0,fuse_segments=4"),
-    # (... and the K-sweep passes with K-plane exchanges inside the capture: the class halos are built by mg_prepare_cycle)
-    (2, 3, 2, 4, 8, 300000, 1, "graph_comm=1,halo_depth=4,fuse_k=4,fuse_min_rows=0,fuse_k_slab_min_rows=0,fuse_k_slab_min_sweeps=2")])
+    (4, 3, 2, 4, 8, 300000, 1, "graph_comm=1,fuse_min_rows=0,fuse_segments=4")])
 def test_slab_cycles_captured_into_graphs_with_their_exchanges(world, dim, lo, hi, c, rep, overlap, tune):
     """`graph_comm`: a slab V-cycle -- sweeps on two streams, grouped send/recv, the grouped broadcasts of the replicated
     levels -- is captured into one hipGraph per rank and replayed.  RCCL's calls are capturable stream operations; the
